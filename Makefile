@@ -1,0 +1,35 @@
+# Top-level build: the product (librt_hip.so: HIP kernels + C ABI; librt_host.so: C++ host side) and the
+# test oracle (oracle/liboracle.so).  Everything is built IN-TREE so that the .so files travel with gpurun.
+#
+# The kernels are built for gfx950 only, with contraction OFF: fused multiply-adds appear only where the source
+# writes them (arithmetic contract v1); sqrt and division stay correctly rounded (hipcc default).
+
+HIPCC    ?= /opt/rocm/bin/hipcc
+CXX      ?= g++
+LIBDIR   := rt_amd/lib
+HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Wno-unused-parameter
+HOSTFLAGS:= -std=c++20 -O2 -fPIC -Wall -Wextra
+
+HIP_SRC  := rt_amd/csrc/kernels.hip rt_amd/csrc/api.hip
+HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp include/rt_hip.h
+HOST_SRC := rt_amd/host/host_capi.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
+HOST_HDR := $(wildcard rt_amd/host/*.hpp) rt_amd/host/host_capi.h rt_amd/host/named_colours.inc include/rt_hip.h
+
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle
+
+$(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+
+$(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
+	@mkdir -p $(LIBDIR)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC)
+
+oracle:
+	$(MAKE) -C oracle
+
+clean:
+	rm -f $(LIBDIR)/*.so
+	$(MAKE) -C oracle clean
+
+.PHONY: all oracle clean

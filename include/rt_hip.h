@@ -1,0 +1,257 @@
+/*
+ * rt_hip.h — C ABI of the MI355X (gfx950) renderer module for marzer/rt.
+ *
+ * This is the drop-in boundary for ONE path of the reference: mg_ray_tracer::render
+ * (reference src/renderers/mg_ray_tracer.cpp:178-205) behind renderer_interface::render
+ * (reference src/renderer.hpp:9-14).  Everything that crosses it is plain C: pointers, sizes,
+ * POD structs.  No C++ types, no exceptions, no torch types.
+ *
+ * The reference-side binding (a ~60 line renderer that gathers the soagen column pointers and
+ * the camera matrix and calls rt_hip_render) is shown in INTEGRATION.md and shim/hip_ray_tracer.cpp.
+ *
+ * Every function that can fail returns an rt_hip_status (0 = success).  On failure a
+ * human-readable message is available from rt_hip_last_error() (thread-local).  The reference's
+ * render() is `noexcept` and returns void (src/renderer.hpp:11); the shim therefore logs the
+ * message in the reference's `error: ...` style (src/main.cpp:43-47) and leaves the caller's
+ * pre-cleared frame (src/main.cpp:318) untouched.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_HIP_ABI_VERSION 1u
+
+typedef enum rt_hip_status
+{
+	RT_HIP_OK				 = 0,
+	RT_HIP_INVALID_ARGUMENT	 = 1, /* null pointer, zero size, out-of-range material index, ... */
+	RT_HIP_NO_DEVICE		 = 2, /* no gfx950 device visible / bad device ordinal */
+	RT_HIP_RUNTIME_ERROR	 = 3, /* a HIP call failed; message carries hipGetErrorString */
+	RT_HIP_NO_SCENE			 = 4, /* render requested before a scene was uploaded */
+	RT_HIP_UNSUPPORTED		 = 5  /* unknown flag bits */
+} rt_hip_status;
+
+/* Material kinds, in the order of `enum class material_type` (reference src/common.hpp:105-115).
+ * mg_ray_tracer shades metal with metal_scatter and EVERYTHING else with lambert_scatter
+ * (reference src/renderers/mg_ray_tracer.cpp:142-152). */
+enum
+{
+	RT_HIP_MATERIAL_LAMBERT	   = 0,
+	RT_HIP_MATERIAL_METAL	   = 1,
+	RT_HIP_MATERIAL_DIELECTRIC = 2,
+	RT_HIP_MATERIAL_AIR		   = 3,
+	RT_HIP_MATERIAL_VACUUM	   = 4,
+	RT_HIP_MATERIAL_WATER	   = 5,
+	RT_HIP_MATERIAL_ICE		   = 6,
+	RT_HIP_MATERIAL_DIAMOND	   = 7,
+	RT_HIP_MATERIAL_COUNT	   = 8
+};
+
+/*
+ * The scene as the renderer sees it: the soagen struct-of-arrays columns of rt::spheres / rt::planes /
+ * rt::materials (reference src/soa.toml:6-33, accessors src/soa.hpp:177-199) plus the two scalars of
+ * rt::scene (reference src/scene.hpp:10-11) and the camera's inverse view-projection for the frame
+ * size being rendered (reference src/camera.hpp:18,122-137).
+ *
+ * All pointers are HOST pointers borrowed for the duration of the call that takes the struct.
+ * Columns hold exactly n_* valid rows; soagen's padding rows past size() are never read
+ * (reference vendor/soagen.hpp:3777,7075-7082).  A count of 0 allows the matching pointers to be NULL.
+ */
+typedef struct rt_hip_scene
+{
+	/* rt::spheres — center_x/center_y/center_z/radius/material columns (src/soa.toml:25-33) */
+	uint32_t n_spheres;
+	const float* sphere_center_x;
+	const float* sphere_center_y;
+	const float* sphere_center_z;
+	const float* sphere_radius;
+	const uint32_t* sphere_material;
+
+	/* rt::planes — normal_x/normal_y/normal_z/d/material columns (src/soa.toml:15-23);
+	 * plane equation n·p + d = 0 with |n| = 1 (src/scene.cpp:580-583) */
+	uint32_t n_planes;
+	const float* plane_normal_x;
+	const float* plane_normal_y;
+	const float* plane_normal_z;
+	const float* plane_d;
+	const uint32_t* plane_material;
+
+	/* rt::materials — type/albedo/roughness/reflectivity columns (src/soa.toml:6-13);
+	 * albedo is rt::colour = 4 floats r,g,b,a per material (src/colour.hpp:17-57) */
+	uint32_t n_materials;
+	const uint32_t* material_type;
+	const float* material_albedo;
+	const float* material_roughness;
+	const float* material_reflectivity;
+
+	/* rt::scene::samples_per_pixel / max_bounces (src/scene.hpp:10-11), both >= 1 */
+	uint32_t samples_per_pixel;
+	uint32_t max_bounces;
+
+	/* viewport::inverse_view_projection for THIS frame size (src/camera.hpp:18,134).
+	 * Fixed order, independent of muu's storage order: element [r*4 + c] = m(r, c), so that
+	 * transform_position(v) = (M * (v.x, v.y, v.z, 1)).xyz / .w  with row r = sum_c m(r,c) * v_c. */
+	float inverse_view_projection[16];
+} rt_hip_scene;
+
+/*
+ * How the image is split across the GPUs of one node: rows are grouped into stripes of `stripe_rows`
+ * rows; stripe b belongs to rank (b % world).  A rank renders only its own stripes into a compact
+ * buffer of rt_hip_local_rows() rows x W pixels (stripe b of the image = stripe b / world of the local
+ * buffer).  Random streams are keyed by the GLOBAL pixel index, so the assembled image does not depend
+ * on `world`.  {0, 1, any} = the whole image.  (New: the reference is single-process,
+ * src/renderers/mg_ray_tracer.cpp:203.)
+ */
+typedef struct rt_hip_partition
+{
+	uint32_t rank;
+	uint32_t world;
+	uint32_t stripe_rows;
+} rt_hip_partition;
+
+#define RT_HIP_DEFAULT_STRIPE_ROWS 8u
+
+/* Work counters of the most recent render on a context (all ranks count their own share). */
+typedef struct rt_hip_stats
+{
+	uint64_t primary_samples; /* pixels rendered by this rank x samples_per_pixel */
+	uint64_t segments;		  /* calls of trace() that did not return at the bounce limit check, i.e. closest-hit queries */
+	uint64_t sphere_tests;	  /* segments x n_spheres */
+	uint64_t plane_tests;	  /* segments x n_planes */
+	float render_ms;		  /* device time of the render kernel(s), HIP events on the launch stream */
+	float upload_ms;		  /* host wall time of the last scene upload */
+	float readback_ms;		  /* host wall time of the last device-to-host frame copy (rt_hip_render only) */
+	uint32_t kernel_variant;  /* which kernel ran: RT_HIP_KERNEL_* */
+} rt_hip_stats;
+
+enum
+{
+	RT_HIP_KERNEL_NONE		= 0,
+	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup */
+	RT_HIP_KERNEL_TILED		= 2	 /* primitives streamed through LDS in tiles (large scenes) */
+};
+
+/* Render flags.  0 = the parity contract: arithmetic bit-identical to oracle/ (see DESIGN.md §3). */
+enum
+{
+	RT_HIP_FLAG_NONE = 0u,
+	/* force the LDS-tiled kernel even for scenes that fit the resident kernel (testing) */
+	RT_HIP_FLAG_FORCE_TILED = 1u << 0
+};
+
+typedef struct rt_hip_ctx rt_hip_ctx;
+
+/* ---- library ---------------------------------------------------------------------------------------------------- */
+
+uint32_t rt_hip_abi_version(void);
+
+/* Message for the most recent failure on the calling thread ("" if none).  Never NULL. */
+const char* rt_hip_last_error(void);
+
+/* Number of visible HIP devices.  Replaces nothing in the reference (CPU-only). */
+rt_hip_status rt_hip_device_count(int* count);
+
+/* ---- context ---------------------------------------------------------------------------------------------------- */
+
+/* One context per GPU per renderer instance; owns the device copy of the scene, the stats block and
+ * staging buffers.  Mirrors the lifetime of a renderer object in the reference: created by
+ * description::create (src/renderer.hpp:39), destroyed through the virtual destructor (src/renderer.hpp:13). */
+rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device);
+void rt_hip_destroy(rt_hip_ctx* ctx);
+
+/* ---- partition helpers (pure host arithmetic; usable without a GPU) ------------------------------------------- */
+
+/* Rows of an H-row image owned by part->rank. */
+rt_hip_status rt_hip_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
+/* max over ranks of rt_hip_local_rows: the per-rank buffer height used for the equal-sized gather. */
+rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
+
+/* ---- the hot path ----------------------------------------------------------------------------------------------- */
+
+/* Copy the scene columns to HBM (once per scene/camera change).  The reference has no scene version
+ * counter (src/main.cpp:233-311), so rt_hip_render() calls this every frame; a caller that knows the
+ * scene is unchanged keeps it resident and calls rt_hip_render_device() only. */
+rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene);
+
+/*
+ * Render this rank's stripes of a width x height frame from the resident scene.
+ *   d_rgba8   DEVICE buffer, padded_local_rows x width uint32, receives RGBA8888 packed exactly as
+ *             rt::colour::operator uint32_t (src/colour.hpp:101-106); row-major, no pitch (src/image.hpp:143-147).
+ *   d_rgb_f32 optional DEVICE buffer, padded_local_rows x width x 3 floats: the per-pixel mean radiance
+ *             before the sqrt "gamma" (mg_ray_tracer.cpp:195), for float-level parity checks.  May be NULL.
+ *   seed      key of the counter-based random streams (the reference seeds from std::random_device,
+ *             src/random.cpp:12-13, and is not reproducible).
+ *   stream    hipStream_t to launch on (NULL = the default stream).  Asynchronous: returns after enqueue.
+ */
+rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
+								   uint32_t width,
+								   uint32_t height,
+								   uint64_t seed,
+								   uint32_t flags,
+								   const rt_hip_partition* part, /* NULL = whole image */
+								   uint32_t* d_rgba8,
+								   float* d_rgb_f32,
+								   void* stream);
+
+/* Rank 0, after the gather: de-interleave `world` compact per-rank buffers (each padded_local_rows x width,
+ * concatenated in rank order) into the width x height frame.  Device to device, asynchronous on `stream`. */
+rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
+									 uint32_t width,
+									 uint32_t height,
+									 uint32_t world,
+									 uint32_t stripe_rows,
+									 const uint32_t* d_gathered,
+									 uint32_t* d_frame,
+									 void* stream);
+
+/* Synchronise with the last render on this context and read its counters. */
+rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats);
+
+/*
+ * The drop-in for renderer_interface::render(const scene&, image_view&, muu::thread_pool&)
+ * (src/renderer.hpp:11; mg_ray_tracer.cpp:178): upload `scene`, render the whole frame on the context's
+ * GPU, and copy it into the caller's HOST pixel buffer (image_view::data(), width*height uint32) before
+ * returning — the caller presents it immediately (src/window.cpp:215-216).
+ *   rgb_f32  optional HOST buffer of 3*width*height floats (pre-gamma mean), may be NULL.
+ *   stats    optional, may be NULL.
+ */
+rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
+							const rt_hip_scene* scene,
+							uint32_t* pixels_rgba8888,
+							uint32_t width,
+							uint32_t height,
+							uint64_t seed,
+							uint32_t flags,
+							float* rgb_f32,
+							rt_hip_stats* stats);
+
+/* ---- known-answer entry points (device implementations of the path's leaf functions, for parity tests) -------- */
+
+/* out[i] = bits of the i-th draw: rt_hip random stream (seed, pixel, sample, draw k) for k in [0, n). */
+rt_hip_status rt_hip_kat_random(rt_hip_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
+
+/* For n rays (origin/direction as 3 floats each, AoS) against the resident scene: closest-hit distance
+ * (< 0 = miss), primitive kind (0 none, 1 sphere, 2 plane), primitive index, and hit normal (3 floats). */
+rt_hip_status rt_hip_kat_closest_hit(rt_hip_ctx* ctx,
+									 uint32_t n,
+									 const float* origins,
+									 const float* directions,
+									 float* out_distance,
+									 uint32_t* out_kind,
+									 uint32_t* out_index,
+									 float* out_normal);
+
+/* out_sqrt[i] = sqrtf(a[i]), out_div[i] = a[i] / b[i] as the device computes them (must be correctly rounded). */
+rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HIP_H */

@@ -1,0 +1,137 @@
+"""ctypes binding of oracle/liboracle.so — TEST INFRASTRUCTURE, NOT PRODUCT.  PARITY UNPINNED (see cpu_ref.h).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.  It takes the same
+``rt_hip_scene`` / ``rt_hip_partition`` PODs as the HIP module so that both see identical bytes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from rt_amd.capi import RtHipPartition, RtHipScene
+
+ORACLE_DIR = Path(__file__).resolve().parent
+TRACE_ITERATIVE = 0
+TRACE_RECURSIVE = 1
+
+
+class OracleStats(C.Structure):
+    _fields_ = [
+        ("primary_samples", C.c_uint64),
+        ("segments", C.c_uint64),
+        ("sphere_tests", C.c_uint64),
+        ("plane_tests", C.c_uint64),
+        ("seconds", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+_lib = None
+
+
+def build() -> Path:
+    subprocess.run(["make", "-C", str(ORACLE_DIR)], check=True, capture_output=True)
+    return ORACLE_DIR / "liboracle.so"
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        path = ORACLE_DIR / "liboracle.so"
+        if not path.exists():
+            build()
+        l = C.CDLL(str(path))
+        l.oracle_render.restype = C.c_int
+        l.oracle_render.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_uint64, C.c_int, C.POINTER(RtHipPartition), C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OracleStats)]
+        l.oracle_render_mt19937.restype = C.c_int
+        l.oracle_render_mt19937.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OracleStats)]
+        l.oracle_random.restype = None
+        l.oracle_random.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        l.oracle_closest_hit.restype = None
+        l.oracle_closest_hit.argtypes = [C.POINTER(RtHipScene), C.c_uint32] + [C.c_void_p] * 6
+        l.oracle_sqrt_div.restype = None
+        l.oracle_sqrt_div.argtypes = [C.c_uint32] + [C.c_void_p] * 4
+        l.oracle_pack.restype = C.c_uint32
+        l.oracle_pack.argtypes = [C.c_float] * 3
+        l.oracle_sky.restype = None
+        l.oracle_sky.argtypes = [C.c_float, C.c_void_p]
+        l.oracle_primary_ray.restype = None
+        l.oracle_primary_ray.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        _lib = l
+    return _lib
+
+
+def _local_rows(height, rank, world, stripe):
+    return sum(1 for y in range(height) if (y // stripe) % world == rank)
+
+
+def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_order: int = TRACE_ITERATIVE, partition=None, want_rgb=True, threads: int = 0):
+    """Counter-RNG strict-IEEE render.  Returns (rgba uint32[rows, W], rgb float32[rows, W, 3] | None, stats dict)."""
+    rows = height if partition is None else _local_rows(height, *partition)
+    rgba = np.zeros((rows, width), dtype=np.uint32)
+    rgb = np.zeros((rows, width, 3), dtype=np.float32) if want_rgb else None
+    stats = OracleStats()
+    part = C.byref(RtHipPartition(*partition)) if partition is not None else None
+    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order, part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render failed ({rc})")
+    return rgba, rgb, stats.as_dict()
+
+
+def render_mt19937(scene: RtHipScene, width: int, height: int, fixed_seed: int = 0, want_rgb=False, threads: int = 0):
+    rgba = np.zeros((height, width), dtype=np.uint32)
+    rgb = np.zeros((height, width, 3), dtype=np.float32) if want_rgb else None
+    stats = OracleStats()
+    rc = lib().oracle_render_mt19937(C.byref(scene), width, height, fixed_seed, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    if rc != 0:
+        raise RuntimeError(f"oracle_render_mt19937 failed ({rc})")
+    return rgba, rgb, stats.as_dict()
+
+
+def random(seed: int, pixel: int, sample: int, n: int) -> np.ndarray:
+    out = np.empty(n, dtype=np.float32)
+    lib().oracle_random(seed, pixel, sample, n, out.ctypes.data)
+    return out
+
+
+def closest_hit(scene: RtHipScene, origins, directions):
+    o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+    d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+    n = len(o)
+    dist = np.empty(n, dtype=np.float32)
+    kind = np.empty(n, dtype=np.uint32)
+    index = np.empty(n, dtype=np.uint32)
+    normal = np.empty((n, 3), dtype=np.float32)
+    lib().oracle_closest_hit(C.byref(scene), n, o.ctypes.data, d.ctypes.data, dist.ctypes.data, kind.ctypes.data, index.ctypes.data, normal.ctypes.data)
+    return dist, kind, index, normal
+
+
+def sqrt_div(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    s = np.empty_like(a)
+    q = np.empty_like(a)
+    lib().oracle_sqrt_div(a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data)
+    return s, q
+
+
+def pack(r: float, g: float, b: float) -> int:
+    return lib().oracle_pack(r, g, b)
+
+
+def sky(dir_y: float) -> np.ndarray:
+    out = np.empty(3, dtype=np.float32)
+    lib().oracle_sky(dir_y, out.ctypes.data)
+    return out
+
+
+def primary_ray(scene: RtHipScene, width: int, height: int, px: float, py: float):
+    o = np.empty(3, dtype=np.float32)
+    d = np.empty(3, dtype=np.float32)
+    lib().oracle_primary_ray(C.byref(scene), width, height, px, py, o.ctypes.data, d.ctypes.data)
+    return o, d

@@ -1,0 +1,588 @@
+// oracle/cpu_ref.cpp — CPU restatement of marzer/rt's mg_ray_tracer hot path (the parity oracle).
+//
+// TEST INFRASTRUCTURE, NOT PRODUCT (see cpu_ref.h).  PARITY UNPINNED (see cpu_ref.h).
+//
+// Follows, function by function (paths relative to the reference root):
+//   render / worker ............ src/renderers/mg_ray_tracer.cpp:178-205
+//   trace ....................... src/renderers/mg_ray_tracer.cpp:155-174
+//   test_planes / test_spheres .. src/renderers/mg_ray_tracer.cpp:36-87
+//   test_boxes / select ......... src/renderers/mg_ray_tracer.cpp:89-102
+//   lambert / metal scatter ..... src/renderers/mg_ray_tracer.cpp:110-140, src/common.hpp:100-103
+//   screen_to_world ............. src/camera.hpp:42-48
+//   random<T>, unit vector ...... src/random.hpp:37-66   (engine replaced: see "random streams")
+//   colour pack ................. src/colour.hpp:63-65,101-106
+//   pixel addressing ............ src/image.hpp:143-159
+//
+// The vector/ray arithmetic itself lives in marzer/muu (absent offline).  The formulas chosen for it are
+// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v1") is this project's own and is what
+// the GPU kernels reproduce bit for bit.  The reference is built with -ffast-math -ffp-contract=fast
+// (meson.build:153-160), so it defines no operation order of its own.
+//
+// Arithmetic contract v1 — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
+// no contraction or reassociation except the fmaf() written out here; sqrtf and '/' are correctly rounded:
+//   dot(a,b)          = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
+//   normalize(v)      = v * (1.0f / sqrtf(dot(v,v)))            (one division, three products)
+//   direction(a,b)    = normalize(b - a)
+//   at(ray,t)         = fmaf(d, t, o) per component
+//   lerp(a,b,t)       = fmaf(b - a, t, a) per component
+//   transform_position(M,v): row_r = fmaf(M[r][0],v.x, fmaf(M[r][1],v.y, fmaf(M[r][2],v.z, M[r][3])));
+//                            xyz = row_0..2 * (1.0f / row_3)
+//   everything else is written out where it is used.
+//
+// Build: -O2 -ffp-contract=off (no -ffast-math); -mfma only makes fmaf() a single instruction.
+
+#include "cpu_ref.h"
+
+#include <atomic>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace
+{
+	struct vec3
+	{
+		float x, y, z;
+	};
+
+	inline vec3 operator+(vec3 a, vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+	inline vec3 operator-(vec3 a, vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+	inline vec3 operator*(vec3 a, vec3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+	inline vec3 operator*(vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+
+	inline float dot(vec3 a, vec3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
+
+	inline vec3 normalize(vec3 v)
+	{
+		const float inv = 1.0f / std::sqrt(dot(v, v));
+		return v * inv;
+	}
+
+	inline vec3 direction(vec3 from, vec3 to) { return normalize(to - from); }
+
+	struct ray
+	{
+		vec3 origin;
+		vec3 dir;
+
+		vec3 at(float t) const
+		{
+			return { std::fmaf(dir.x, t, origin.x), std::fmaf(dir.y, t, origin.y), std::fmaf(dir.z, t, origin.z) };
+		}
+	};
+
+	// ---- random streams -------------------------------------------------------------------------------------
+	// The reference draws from a thread_local std::mt19937 seeded by std::random_device (src/random.cpp:9-26):
+	// not reproducible, and tied to which host thread ran the pixel.  Replaced by a counter-based stream keyed by
+	// (seed, GLOBAL pixel index, sample index); draw k of a sample is a pure function of those four numbers.
+	//   hash32  = the "lowbias32" integer finaliser (xorshift-multiply, two rounds)
+	//   frame   = hash32(lo32(seed) ^ hash32(hi32(seed) ^ 0x9E3779B9))
+	//   pixel   = hash32(frame ^ pixel_index)
+	//   counter = hash32(pixel + sample_index)
+	//   draw    : counter += 0x9E3779B9;  u = float(hash32(counter) >> 8) * 2^-24      in [0, 1)
+	inline uint32_t hash32(uint32_t x)
+	{
+		x ^= x >> 16;
+		x *= 0x7feb352du;
+		x ^= x >> 15;
+		x *= 0x846ca68bu;
+		x ^= x >> 16;
+		return x;
+	}
+
+	inline uint32_t frame_key(uint64_t seed)
+	{
+		return hash32(static_cast<uint32_t>(seed) ^ hash32(static_cast<uint32_t>(seed >> 32) ^ 0x9E3779B9u));
+	}
+
+	struct random_stream
+	{
+		uint32_t counter;
+
+		random_stream(uint32_t frame, uint32_t pixel_index, uint32_t sample_index)
+			: counter{ hash32(hash32(frame ^ pixel_index) + sample_index) }
+		{}
+
+		// random<float>(), src/random.hpp:12-17 / src/random.cpp:20-26: uniform in [0, 1)
+		float next()
+		{
+			counter += 0x9E3779B9u;
+			return static_cast<float>(hash32(counter) >> 8) * 0x1.0p-24f;
+		}
+	};
+
+	// random_unit_vector(), src/random.hpp:57-66: components drawn x, y, z (brace-init order, :43-46), redrawn
+	// only if exactly zero, then normalised.  All components are >= 0: the direction lies in the positive octant.
+	inline vec3 random_unit_vector(random_stream& rng)
+	{
+		while (true)
+		{
+			const float x = rng.next();
+			const float y = rng.next();
+			const float z = rng.next();
+			if (x == 0.0f && y == 0.0f && z == 0.0f)
+				continue;
+			return normalize({ x, y, z });
+		}
+	}
+
+	// ---- scene access -----------------------------------------------------------------------------------------
+	struct material
+	{
+		uint32_t type;
+		vec3 attenuation; // vec3{ albedo * reflectivity }, mg_ray_tracer.cpp:115,131 (colour * float, colour.hpp:144-149)
+		float roughness;
+	};
+
+	struct frame
+	{
+		const rt_hip_scene* scene;
+		std::vector<material> materials;
+		uint32_t width, height;
+		float sx, sy; // 2 / W, 2 / H
+		uint32_t frame_key;
+		int trace_order;
+	};
+
+	inline frame make_frame(const rt_hip_scene* s, uint32_t w, uint32_t h, uint64_t seed, int trace_order)
+	{
+		frame f{};
+		f.scene = s;
+		f.width = w;
+		f.height = h;
+		f.sx = 2.0f / static_cast<float>(w);
+		f.sy = 2.0f / static_cast<float>(h);
+		f.frame_key = frame_key(seed);
+		f.trace_order = trace_order;
+		f.materials.resize(s->n_materials);
+		for (uint32_t m = 0; m < s->n_materials; m++)
+		{
+			const float refl = s->material_reflectivity[m];
+			f.materials[m].type = s->material_type[m];
+			f.materials[m].attenuation = { s->material_albedo[m * 4 + 0] * refl,
+										   s->material_albedo[m * 4 + 1] * refl,
+										   s->material_albedo[m * 4 + 2] * refl };
+			f.materials[m].roughness = s->material_roughness[m];
+		}
+		return f;
+	}
+
+	// ---- camera: viewport::screen_to_world, src/camera.hpp:42-48 -------------------------------------------------
+	inline vec3 transform_position(const float* M, vec3 v)
+	{
+		float row[4];
+		for (int r = 0; r < 4; r++)
+			row[r] = std::fmaf(M[r * 4 + 0], v.x, std::fmaf(M[r * 4 + 1], v.y, std::fmaf(M[r * 4 + 2], v.z, M[r * 4 + 3])));
+		const float inv_w = 1.0f / row[3];
+		return { row[0] * inv_w, row[1] * inv_w, row[2] * inv_w };
+	}
+
+	inline vec3 screen_to_world(const frame& f, float px, float py, float depth)
+	{
+		// { 2*(x/W) - 1, -2*(y/H) + 1, depth }, with 2/W and 2/H hoisted per frame
+		const vec3 ndc = { std::fmaf(px, f.sx, -1.0f), std::fmaf(py, -f.sy, 1.0f), depth };
+		return transform_position(f.scene->inverse_view_projection, ndc);
+	}
+
+	inline ray primary_ray(const frame& f, float px, float py)
+	{
+		const vec3 near_pos = screen_to_world(f, px, py, 0.0f); // mg_ray_tracer.cpp:190
+		const vec3 far_pos = screen_to_world(f, px, py, 1.0f);	// :191
+		return { near_pos, direction(near_pos, far_pos) };		// :193
+	}
+
+	// ---- intersection (muu::ray::hits; formulas per SURVEY.md §8c) ------------------------------------------------
+	constexpr float min_hit_dist = 0.001f; // mg_ray_tracer.cpp:20
+	constexpr float approx_zero_epsilon = 1.0e-6f;
+
+	// returns false = no hit (std::nullopt in muu)
+	inline bool hits_sphere(const ray& r, vec3 center, float radius, float& t)
+	{
+		const vec3 e = center - r.origin;
+		const float a = dot(e, r.dir);
+		const float e2 = dot(e, e);
+		const float r2 = radius * radius;
+		const float disc = r2 - std::fmaf(-a, a, e2); // r^2 - (e^2 - a^2)
+		if (disc < 0.0f)
+			return false;
+		const float f = std::sqrt(disc);
+		t = (e2 < r2) ? a + f : a - f; // origin inside: far root; outside: near root
+		if (t < 0.0f)
+			return false;
+		return true;
+	}
+
+	// plane: n·p + d = 0
+	inline bool hits_plane(const ray& r, vec3 n, float d, float& t)
+	{
+		const float den = dot(n, r.dir);
+		if (std::fabs(den) <= approx_zero_epsilon)
+			return false;
+		const float num = dot(n, r.origin) + d;
+		t = (-num) / den;
+		if (t < 0.0f)
+			return false;
+		return true;
+	}
+
+	struct hit_result // mg_ray_tracer.cpp:22-33
+	{
+		float distance;
+		vec3 normal;
+		uint32_t material;
+		uint32_t kind; // 0 none, 1 sphere, 2 plane (diagnostic only)
+		uint32_t index;
+
+		explicit operator bool() const { return distance >= 0.0f; }
+	};
+
+	constexpr hit_result no_hit = { -1.0f, { 0, 0, 0 }, 0, 0, 0 };
+
+	// mg_ray_tracer.cpp:36-60
+	inline hit_result test_planes(const rt_hip_scene& s, const ray& r)
+	{
+		bool have = false;
+		uint32_t hit_index = 0;
+		float hit_dist = 0.0f;
+		for (uint32_t i = 0; i < s.n_planes; i++)
+		{
+			float t;
+			const bool hit = hits_plane(r, { s.plane_normal_x[i], s.plane_normal_y[i], s.plane_normal_z[i] }, s.plane_d[i], t);
+			if (!hit || t < min_hit_dist || (have && hit_dist <= t))
+				continue;
+			have = true;
+			hit_index = i;
+			hit_dist = t;
+		}
+		if (!have)
+			return no_hit;
+		return { hit_dist,
+				 { s.plane_normal_x[hit_index], s.plane_normal_y[hit_index], s.plane_normal_z[hit_index] },
+				 s.plane_material[hit_index],
+				 2u,
+				 hit_index };
+	}
+
+	// mg_ray_tracer.cpp:63-87
+	inline hit_result test_spheres(const rt_hip_scene& s, const ray& r)
+	{
+		bool have = false;
+		uint32_t hit_index = 0;
+		float hit_dist = 0.0f;
+		for (uint32_t i = 0; i < s.n_spheres; i++)
+		{
+			float t;
+			const bool hit =
+				hits_sphere(r, { s.sphere_center_x[i], s.sphere_center_y[i], s.sphere_center_z[i] }, s.sphere_radius[i], t);
+			if (!hit || t < min_hit_dist || (have && hit_dist <= t))
+				continue;
+			have = true;
+			hit_index = i;
+			hit_dist = t;
+		}
+		if (!have)
+			return no_hit;
+		const vec3 center = { s.sphere_center_x[hit_index], s.sphere_center_y[hit_index], s.sphere_center_z[hit_index] };
+		return { hit_dist, direction(center, r.at(hit_dist)), s.sphere_material[hit_index], 1u, hit_index };
+	}
+
+	// mg_ray_tracer.cpp:96-102
+	inline hit_result select(const hit_result& a, const hit_result& b)
+	{
+		if (!a)
+			return b;
+		return (!b || a.distance <= b.distance) ? a : b;
+	}
+
+	inline hit_result closest_hit(const rt_hip_scene& s, const ray& r)
+	{
+		hit_result hit = test_planes(s, r);	  // :160
+		hit = select(test_spheres(s, r), hit); // :161  (sphere wins a tie)
+		hit = select(no_hit, hit);			  // :162  test_boxes always misses (:89-93)
+		return hit;
+	}
+
+	// ---- shading ---------------------------------------------------------------------------------------------
+	// mg_ray_tracer.cpp:164 — lerp(white, (0.5, 0.7, 1.0), 0.5 * (dir.y + 1))
+	inline vec3 sky(float dir_y)
+	{
+		const float t = 0.5f * (dir_y + 1.0f);
+		const vec3 a = { 1.0f, 1.0f, 1.0f };
+		const vec3 b = { 0.5f, 0.7f, 1.0f };
+		return { std::fmaf(b.x - a.x, t, a.x), std::fmaf(b.y - a.y, t, a.y), std::fmaf(b.z - a.z, t, a.z) };
+	}
+
+	// mg_ray_tracer.cpp:110-123
+	inline bool lambert_scatter(const ray& r, const hit_result& hit, random_stream& rng, ray& out)
+	{
+		vec3 scatter = hit.normal + random_unit_vector(rng);
+		if (std::fabs(scatter.x) <= approx_zero_epsilon && std::fabs(scatter.y) <= approx_zero_epsilon
+			&& std::fabs(scatter.z) <= approx_zero_epsilon)
+			scatter = hit.normal;
+		out = { r.at(hit.distance), normalize(scatter) };
+		return true;
+	}
+
+	// mg_ray_tracer.cpp:126-140; reflect = v - 2*dot(v,n)*n, src/common.hpp:100-103
+	inline bool metal_scatter(const ray& r, const hit_result& hit, float roughness, random_stream& rng, ray& out)
+	{
+		const vec3 v = normalize(r.dir);
+		const float k = 2.0f * dot(v, hit.normal);
+		const vec3 reflected = { std::fmaf(-k, hit.normal.x, v.x), std::fmaf(-k, hit.normal.y, v.y), std::fmaf(-k, hit.normal.z, v.z) };
+		const vec3 u = random_unit_vector(rng);
+		const vec3 scatter = { std::fmaf(roughness, u.x, reflected.x),
+							   std::fmaf(roughness, u.y, reflected.y),
+							   std::fmaf(roughness, u.z, reflected.z) };
+		if (dot(scatter, hit.normal) <= 0.0f)
+			return false;
+		out = { r.at(hit.distance), normalize(scatter) };
+		return true;
+	}
+
+	// scatter_funcs table, mg_ray_tracer.cpp:142-152: metal -> metal_scatter, everything else -> lambert_scatter
+	inline bool scatter(const frame& f, const ray& r, const hit_result& hit, random_stream& rng, ray& out, vec3& attenuation)
+	{
+		const material& m = f.materials[hit.material];
+		attenuation = m.attenuation;
+		if (m.type == RT_HIP_MATERIAL_METAL)
+			return metal_scatter(r, hit, m.roughness, rng, out);
+		return lambert_scatter(r, hit, rng, out);
+	}
+
+	struct counters
+	{
+		uint64_t segments = 0;
+	};
+
+	// mg_ray_tracer.cpp:155-174, literal recursion
+	vec3 trace_recursive(const frame& f, const ray& r, uint32_t max_bounces, random_stream& rng, counters& c)
+	{
+		if (!(max_bounces--))
+			return { 0, 0, 0 };
+		c.segments++;
+		const hit_result hit = closest_hit(*f.scene, r);
+		if (!hit)
+			return sky(r.dir.y);
+		vec3 attenuation;
+		ray scattered;
+		if (scatter(f, r, hit, rng, scattered, attenuation))
+			return attenuation * trace_recursive(f, scattered, max_bounces, rng, c);
+		return { 0, 0, 0 };
+	}
+
+	// The same function with the recursion unrolled front to back: the product of attenuations is carried
+	// forward ("throughput") and multiplied into the sky colour at the end.  Mathematically identical to the
+	// recursion; the products associate left-to-right instead of right-to-left.  THIS is the order of the
+	// arithmetic contract (a GPU lane cannot recurse cheaply; the reference's own -ffast-math build does not
+	// pin an association either).
+	vec3 trace_iterative(const frame& f, ray r, uint32_t max_bounces, random_stream& rng, counters& c)
+	{
+		vec3 throughput = { 1.0f, 1.0f, 1.0f };
+		while (true)
+		{
+			if (!(max_bounces--))
+				return { 0, 0, 0 };
+			c.segments++;
+			const hit_result hit = closest_hit(*f.scene, r);
+			if (!hit)
+				return throughput * sky(r.dir.y);
+			vec3 attenuation;
+			ray scattered;
+			if (!scatter(f, r, hit, rng, scattered, attenuation))
+				return { 0, 0, 0 };
+			throughput = throughput * attenuation;
+			r = scattered;
+		}
+	}
+
+	inline float clamp01(float x) { return x > 1.0f ? 1.0f : (x >= 0.0f ? x : 0.0f); } // NaN -> 0
+
+	// rt::colour{vec3} (a = 1) -> uint32, src/colour.hpp:63-65,101-106
+	inline uint32_t pack(vec3 c)
+	{
+		const uint32_t r = static_cast<uint32_t>(clamp01(c.x) * 255.99999f);
+		const uint32_t g = static_cast<uint32_t>(clamp01(c.y) * 255.99999f);
+		const uint32_t b = static_cast<uint32_t>(clamp01(c.z) * 255.99999f);
+		const uint32_t a = static_cast<uint32_t>(clamp01(1.0f) * 255.99999f);
+		return (r << 24u) | (g << 16u) | (b << 8u) | a;
+	}
+
+	// worker lambda, mg_ray_tracer.cpp:182-201, for the pixel at (x, y)
+	inline void render_pixel(const frame& f, uint32_t x, uint32_t y, uint32_t& out_rgba, float* out_rgb, counters& c)
+	{
+		const rt_hip_scene& s = *f.scene;
+		const uint32_t pixel_index = y * f.width + x; // image_view::position_of inverse, src/image.hpp:155-159
+		vec3 colour = { 0, 0, 0 };
+		for (uint32_t i = 0, e = s.samples_per_pixel; i < e; i++)
+		{
+			random_stream rng{ f.frame_key, pixel_index, i };
+			float jx = 0.5f, jy = 0.5f; // sample 0 goes through the pixel centre (:189)
+			if (i)
+			{
+				jx = rng.next();
+				jy = rng.next();
+			}
+			const float px = static_cast<float>(x) + jx;
+			const float py = static_cast<float>(y) + jy;
+			const ray r = primary_ray(f, px, py);
+			const vec3 sample = f.trace_order == ORACLE_TRACE_RECURSIVE ? trace_recursive(f, r, s.max_bounces, rng, c)
+																		 : trace_iterative(f, r, s.max_bounces, rng, c);
+			colour = colour + sample;
+		}
+		const float n = static_cast<float>(s.samples_per_pixel);
+		colour = { colour.x / n, colour.y / n, colour.z / n }; // :195
+		if (out_rgb)
+		{
+			out_rgb[0] = colour.x;
+			out_rgb[1] = colour.y;
+			out_rgb[2] = colour.z;
+		}
+		colour = { std::sqrt(colour.x), std::sqrt(colour.y), std::sqrt(colour.z) }; // :196-198
+		out_rgba = pack(colour);													 // :200
+	}
+
+	inline uint32_t local_rows_of(uint32_t height, uint32_t rank, uint32_t world, uint32_t stripe)
+	{
+		uint32_t rows = 0;
+		for (uint32_t y0 = 0, b = 0; y0 < height; y0 += stripe, b++)
+			if (b % world == rank)
+				rows += (height - y0 < stripe) ? height - y0 : stripe;
+		return rows;
+	}
+}
+
+extern "C" int oracle_render(const rt_hip_scene* scene,
+							 uint32_t width,
+							 uint32_t height,
+							 uint64_t seed,
+							 int trace_order,
+							 const rt_hip_partition* part,
+							 uint32_t* rgba8,
+							 float* rgb_f32,
+							 int n_threads,
+							 oracle_stats* stats)
+{
+	if (!scene || !rgba8 || !width || !height || !scene->samples_per_pixel || !scene->max_bounces)
+		return 1;
+	const rt_hip_partition whole = { 0, 1, RT_HIP_DEFAULT_STRIPE_ROWS };
+	const rt_hip_partition p = part ? *part : whole;
+	if (!p.world || p.rank >= p.world || !p.stripe_rows)
+		return 1;
+
+	const frame f = make_frame(scene, width, height, seed, trace_order);
+
+	// rows owned by this rank, in local order
+	std::vector<uint32_t> rows;
+	for (uint32_t y = 0; y < height; y++)
+		if ((y / p.stripe_rows) % p.world == p.rank)
+			rows.push_back(y);
+
+	unsigned threads = n_threads > 0 ? static_cast<unsigned>(n_threads) : std::thread::hardware_concurrency();
+	if (!threads)
+		threads = 1;
+	if (threads > rows.size())
+		threads = rows.empty() ? 1u : static_cast<unsigned>(rows.size());
+
+	std::atomic<size_t> next_row{ 0 };
+	std::atomic<uint64_t> segments{ 0 };
+	const auto t0 = std::chrono::steady_clock::now();
+	const auto body = [&]()
+	{
+		counters c;
+		for (size_t local_y = next_row++; local_y < rows.size(); local_y = next_row++)
+		{
+			const uint32_t y = rows[local_y];
+			for (uint32_t x = 0; x < width; x++)
+			{
+				const size_t o = local_y * width + x;
+				render_pixel(f, x, y, rgba8[o], rgb_f32 ? rgb_f32 + o * 3 : nullptr, c);
+			}
+		}
+		segments += c.segments;
+	};
+	std::vector<std::thread> pool;
+	for (unsigned t = 1; t < threads; t++)
+		pool.emplace_back(body);
+	body();
+	for (auto& t : pool)
+		t.join();
+	const auto t1 = std::chrono::steady_clock::now();
+
+	if (stats)
+	{
+		stats->primary_samples = static_cast<uint64_t>(rows.size()) * width * scene->samples_per_pixel;
+		stats->segments = segments.load();
+		stats->sphere_tests = stats->segments * scene->n_spheres;
+		stats->plane_tests = stats->segments * scene->n_planes;
+		stats->seconds = std::chrono::duration<double>(t1 - t0).count();
+	}
+	(void)local_rows_of;
+	return 0;
+}
+
+extern "C" void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
+{
+	random_stream rng{ frame_key(seed), pixel, sample };
+	for (uint32_t i = 0; i < n; i++)
+		out[i] = rng.next();
+}
+
+extern "C" void oracle_closest_hit(const rt_hip_scene* scene,
+								   uint32_t n,
+								   const float* origins,
+								   const float* directions,
+								   float* out_distance,
+								   uint32_t* out_kind,
+								   uint32_t* out_index,
+								   float* out_normal)
+{
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const ray r = { { origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2] },
+						{ directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2] } };
+		const hit_result h = closest_hit(*scene, r);
+		out_distance[i] = h.distance;
+		out_kind[i] = h.kind;
+		out_index[i] = h.index;
+		out_normal[i * 3 + 0] = h.normal.x;
+		out_normal[i * 3 + 1] = h.normal.y;
+		out_normal[i * 3 + 2] = h.normal.z;
+	}
+}
+
+extern "C" void oracle_sqrt_div(uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div)
+{
+	for (uint32_t i = 0; i < n; i++)
+	{
+		out_sqrt[i] = std::sqrt(a[i]);
+		out_div[i] = a[i] / b[i];
+	}
+}
+
+extern "C" uint32_t oracle_pack(float r, float g, float b)
+{
+	return pack({ r, g, b });
+}
+
+extern "C" void oracle_sky(float dir_y, float* out_rgb)
+{
+	const vec3 c = sky(dir_y);
+	out_rgb[0] = c.x;
+	out_rgb[1] = c.y;
+	out_rgb[2] = c.z;
+}
+
+extern "C" void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir)
+{
+	const frame f = make_frame(scene, width, height, 0, ORACLE_TRACE_ITERATIVE);
+	const ray r = primary_ray(f, px, py);
+	out_origin[0] = r.origin.x;
+	out_origin[1] = r.origin.y;
+	out_origin[2] = r.origin.z;
+	out_dir[0] = r.dir.x;
+	out_dir[1] = r.dir.y;
+	out_dir[2] = r.dir.z;
+}

@@ -1,0 +1,87 @@
+/*
+ * oracle/cpu_ref.h — C entry points of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * `cpu_baseline` leg may load liboracle.so; nothing under rt_amd/ links, imports or calls it.
+ *
+ * PARITY UNPINNED: the reference (marzer/rt) ships no tests, golden images or known-answer vectors,
+ * cannot be built offline (its math library marzer/muu @ 06dbcecb6e6c8192d24c0d3dc98260b1144c2d70 is a
+ * network-fetched meson wrap, subprojects/muu.wrap:1-8) and is non-deterministic by construction
+ * (src/random.cpp:12-13).  This oracle is a restatement of src/renderers/mg_ray_tracer.cpp pinned only by
+ * analytic known-answer tests derived from the reference's source (tests/test_oracle_kat.py).
+ *
+ * Scene and partition structs are the public ABI types of include/rt_hip.h so that the same bytes can be
+ * handed to the oracle and to the HIP module.
+ */
+#ifndef RT_ORACLE_CPU_REF_H
+#define RT_ORACLE_CPU_REF_H
+
+#include "../include/rt_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct oracle_stats
+{
+	uint64_t primary_samples;
+	uint64_t segments;
+	uint64_t sphere_tests;
+	uint64_t plane_tests;
+	double seconds; /* wall time of the render loop */
+} oracle_stats;
+
+/* trace() evaluation order */
+enum
+{
+	ORACLE_TRACE_ITERATIVE = 0, /* the arithmetic contract shared with the GPU (forward throughput product) */
+	ORACLE_TRACE_RECURSIVE = 1	/* literal recursion of mg_ray_tracer.cpp:155-174 (attenuation * trace(...)) */
+};
+
+/* Counter-RNG, strict IEEE render: the parity oracle.  rgba8 / rgb_f32 are local_rows x width (compact
+ * stripes of `part`, see rt_hip_partition); part == NULL renders the whole frame.  n_threads <= 0 = all cores.
+ * Returns 0 on success. */
+int oracle_render(const rt_hip_scene* scene,
+				  uint32_t width,
+				  uint32_t height,
+				  uint64_t seed,
+				  int trace_order,
+				  const rt_hip_partition* part,
+				  uint32_t* rgba8,
+				  float* rgb_f32, /* nullable */
+				  int n_threads,
+				  oracle_stats* stats /* nullable */);
+
+/* Reference-faithful COST model of mg_ray_tracer (AoS primitives, recursion, std::optional, function-pointer
+ * scatter table, thread_local std::mt19937 + uniform_real_distribution<float>), built with the reference's
+ * release flags (-O3 -ffast-math -ffp-contract=fast -mfma -mavx2).  Not reproducible (random_device seed unless
+ * fixed_seed != 0); used for the CPU baseline timing and for statistical checks only. */
+int oracle_render_mt19937(const rt_hip_scene* scene,
+						  uint32_t width,
+						  uint32_t height,
+						  uint32_t fixed_seed,
+						  uint32_t* rgba8,
+						  float* rgb_f32, /* nullable */
+						  int n_threads,
+						  oracle_stats* stats /* nullable */);
+
+/* Leaf functions, for known-answer tests and device KATs. */
+void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
+void oracle_closest_hit(const rt_hip_scene* scene,
+						uint32_t n,
+						const float* origins,
+						const float* directions,
+						float* out_distance,
+						uint32_t* out_kind,
+						uint32_t* out_index,
+						float* out_normal);
+void oracle_sqrt_div(uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
+uint32_t oracle_pack(float r, float g, float b);			   /* rt::colour{vec3} -> uint32, colour.hpp:63-65,101-106 */
+void oracle_sky(float dir_y, float* out_rgb);				   /* mg_ray_tracer.cpp:164 */
+void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,558 @@
+// rt_amd/csrc/api.hip — the C ABI of include/rt_hip.h on top of the gfx950 kernels.
+//
+// Host-side only: argument checking, HBM residency of the scene columns, launches, the device-to-host frame
+// copy of the drop-in rt_hip_render(), error translation.  No exceptions leave this file; every HIP error is
+// turned into RT_HIP_RUNTIME_ERROR + a message (the reference's render() is noexcept, src/renderer.hpp:11).
+#include "../../include/rt_hip.h"
+#include "contract.hpp"
+#include "kernels.hpp"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace rt_hip;
+
+namespace
+{
+	thread_local std::string g_last_error;
+
+	rt_hip_status fail(rt_hip_status status, const char* format, ...)
+	{
+		char buffer[512];
+		va_list args;
+		va_start(args, format);
+		std::vsnprintf(buffer, sizeof(buffer), format, args);
+		va_end(args);
+		g_last_error = buffer;
+		return status;
+	}
+
+	rt_hip_status ok()
+	{
+		return RT_HIP_OK;
+	}
+
+#define RT_HIP_TRY(expr)                                                                                               \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		const hipError_t rt_hip_try_err = (expr);                                                                      \
+		if (rt_hip_try_err != hipSuccess)                                                                              \
+			return fail(RT_HIP_RUNTIME_ERROR, "%s failed: %s", #expr, hipGetErrorString(rt_hip_try_err));              \
+	}                                                                                                                  \
+	while (false)
+
+	// grow-only device allocation
+	struct device_buffer
+	{
+		void* ptr = nullptr;
+		size_t bytes = 0;
+
+		hipError_t reserve(size_t wanted)
+		{
+			if (wanted <= bytes)
+				return hipSuccess;
+			if (ptr)
+			{
+				(void)hipFree(ptr);
+				ptr = nullptr;
+				bytes = 0;
+			}
+			const hipError_t e = hipMalloc(&ptr, wanted);
+			if (e == hipSuccess)
+				bytes = wanted;
+			return e;
+		}
+		void release()
+		{
+			if (ptr)
+				(void)hipFree(ptr);
+			ptr = nullptr;
+			bytes = 0;
+		}
+		template <typename T>
+		T* as() const
+		{
+			return static_cast<T*>(ptr);
+		}
+	};
+
+	double seconds_since(std::chrono::steady_clock::time_point t0)
+	{
+		return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+	}
+
+	bool valid_partition(const rt_hip_partition& p)
+	{
+		return p.world && p.rank < p.world && p.stripe_rows;
+	}
+
+	uint32_t local_rows_of(uint32_t height, uint32_t rank, uint32_t world, uint32_t stripe_rows)
+	{
+		const uint32_t stripes = (height + stripe_rows - 1) / stripe_rows;
+		uint32_t rows = 0;
+		for (uint32_t b = rank; b < stripes; b += world)
+		{
+			const uint32_t y0 = b * stripe_rows;
+			rows += (height - y0 < stripe_rows) ? height - y0 : stripe_rows;
+		}
+		return rows;
+	}
+}
+
+struct rt_hip_ctx
+{
+	int device = 0;
+
+	// the scene, resident in HBM: one buffer holding every column back to back (256-byte aligned starts)
+	device_buffer scene_columns;
+	device_scene scene{};
+	bool have_scene = false;
+	uint32_t samples_per_pixel = 0, max_bounces = 0;
+	float inverse_view_projection[16]{};
+
+	device_buffer counters;
+	hipEvent_t render_begin = nullptr, render_end = nullptr;
+	bool render_recorded = false;
+	hipStream_t last_stream = nullptr;
+
+	// staging for the drop-in rt_hip_render()
+	device_buffer frame_rgba, frame_rgb;
+
+	// KAT scratch
+	device_buffer kat_in, kat_out;
+
+	rt_hip_stats stats{};
+};
+
+extern "C" uint32_t rt_hip_abi_version(void)
+{
+	return RT_HIP_ABI_VERSION;
+}
+
+extern "C" const char* rt_hip_last_error(void)
+{
+	return g_last_error.c_str();
+}
+
+extern "C" rt_hip_status rt_hip_device_count(int* count)
+{
+	if (!count)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_device_count: count is NULL");
+	*count = 0;
+	const hipError_t e = hipGetDeviceCount(count);
+	if (e == hipErrorNoDevice)
+	{
+		*count = 0;
+		return ok();
+	}
+	RT_HIP_TRY(e);
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device)
+{
+	if (!out_ctx)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create: out_ctx is NULL");
+	*out_ctx = nullptr;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+		return fail(RT_HIP_NO_DEVICE, "rt_hip_create: no HIP device is visible");
+	if (device < 0 || device >= count)
+		return fail(RT_HIP_NO_DEVICE, "rt_hip_create: device %d out of range (%d visible)", device, count);
+	RT_HIP_TRY(hipSetDevice(device));
+	hipDeviceProp_t props{};
+	RT_HIP_TRY(hipGetDeviceProperties(&props, device));
+	if (std::strncmp(props.gcnArchName, "gfx950", 6) != 0)
+		return fail(RT_HIP_NO_DEVICE, "rt_hip_create: device %d is %s; this module is built for gfx950 only", device, props.gcnArchName);
+
+	rt_hip_ctx* ctx = new (std::nothrow) rt_hip_ctx;
+	if (!ctx)
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create: out of host memory");
+	ctx->device = device;
+	hipError_t e = ctx->counters.reserve(sizeof(device_counters));
+	if (e == hipSuccess)
+		e = hipEventCreate(&ctx->render_begin);
+	if (e == hipSuccess)
+		e = hipEventCreate(&ctx->render_end);
+	if (e != hipSuccess)
+	{
+		rt_hip_destroy(ctx);
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create: %s", hipGetErrorString(e));
+	}
+	*out_ctx = ctx;
+	return ok();
+}
+
+extern "C" void rt_hip_destroy(rt_hip_ctx* ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	(void)hipDeviceSynchronize();
+	ctx->scene_columns.release();
+	ctx->counters.release();
+	ctx->frame_rgba.release();
+	ctx->frame_rgb.release();
+	ctx->kat_in.release();
+	ctx->kat_out.release();
+	if (ctx->render_begin)
+		(void)hipEventDestroy(ctx->render_begin);
+	if (ctx->render_end)
+		(void)hipEventDestroy(ctx->render_end);
+	delete ctx;
+}
+
+extern "C" rt_hip_status rt_hip_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows)
+{
+	if (!out_rows || !part || !valid_partition(*part))
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_local_rows: invalid partition");
+	*out_rows = local_rows_of(height, part->rank, part->world, part->stripe_rows);
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows)
+{
+	if (!out_rows || !part || !part->world || !part->stripe_rows)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_padded_local_rows: invalid partition");
+	// rank 0 always owns the most rows: it gets the first stripe of every round
+	*out_rows = local_rows_of(height, 0, part->world, part->stripe_rows);
+	// ...except that a ragged LAST stripe may land on rank 0 while another rank holds a full one
+	for (uint32_t r = 1; r < part->world; r++)
+	{
+		const uint32_t rows = local_rows_of(height, r, part->world, part->stripe_rows);
+		if (rows > *out_rows)
+			*out_rows = rows;
+	}
+	return ok();
+}
+
+namespace
+{
+	rt_hip_status check_scene(const rt_hip_scene& s)
+	{
+		if (!s.samples_per_pixel || !s.max_bounces)
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: samples_per_pixel and max_bounces must be >= 1");
+		if (s.n_spheres && (!s.sphere_center_x || !s.sphere_center_y || !s.sphere_center_z || !s.sphere_radius || !s.sphere_material))
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u spheres but a sphere column is NULL", s.n_spheres);
+		if (s.n_planes && (!s.plane_normal_x || !s.plane_normal_y || !s.plane_normal_z || !s.plane_d || !s.plane_material))
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u planes but a plane column is NULL", s.n_planes);
+		if (!s.n_materials && (s.n_spheres || s.n_planes))
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: primitives present but no materials");
+		if (s.n_materials && (!s.material_type || !s.material_albedo || !s.material_roughness || !s.material_reflectivity))
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u materials but a material column is NULL", s.n_materials);
+		// the reference's loader rejects out-of-range material indices (src/scene.cpp:568-574); an index that got
+		// past it would read out of bounds on the device, so it is refused here too
+		for (uint32_t i = 0; i < s.n_spheres; i++)
+			if (s.sphere_material[i] >= s.n_materials)
+				return fail(RT_HIP_INVALID_ARGUMENT, "scene: sphere %u has material index %u out-of-range", i, s.sphere_material[i]);
+		for (uint32_t i = 0; i < s.n_planes; i++)
+			if (s.plane_material[i] >= s.n_materials)
+				return fail(RT_HIP_INVALID_ARGUMENT, "scene: plane %u has material index %u out-of-range", i, s.plane_material[i]);
+		return ok();
+	}
+
+	constexpr size_t align_up(size_t v, size_t a)
+	{
+		return (v + a - 1) / a * a;
+	}
+}
+
+extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
+{
+	if (!ctx || !scene)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_scene_upload: NULL argument");
+	if (const rt_hip_status st = check_scene(*scene))
+		return st;
+	const auto t0 = std::chrono::steady_clock::now();
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+
+	const rt_hip_scene& s = *scene;
+	// layout of the single HBM block: every column starts on a 256-byte boundary
+	constexpr size_t column_alignment = 256;
+	size_t offset = 0;
+	const auto place = [&](size_t bytes)
+	{
+		const size_t at = offset;
+		offset = align_up(offset + bytes, column_alignment);
+		return at;
+	};
+	const size_t sphere_bytes = static_cast<size_t>(s.n_spheres) * 4;
+	const size_t plane_bytes = static_cast<size_t>(s.n_planes) * 4;
+	const size_t o_scx = place(sphere_bytes), o_scy = place(sphere_bytes), o_scz = place(sphere_bytes), o_sr = place(sphere_bytes), o_sm = place(sphere_bytes);
+	const size_t o_pnx = place(plane_bytes), o_pny = place(plane_bytes), o_pnz = place(plane_bytes), o_pd = place(plane_bytes), o_pm = place(plane_bytes);
+	const size_t o_shading = place(static_cast<size_t>(s.n_materials) * sizeof(float4));
+	const size_t o_type = place(static_cast<size_t>(s.n_materials) * 4);
+	const size_t total = offset ? offset : column_alignment;
+
+	// host image of the block (one H2D copy)
+	std::vector<unsigned char> host(total, 0);
+	const auto put = [&](size_t at, const void* src, size_t bytes)
+	{
+		if (bytes)
+			std::memcpy(host.data() + at, src, bytes);
+	};
+	put(o_scx, s.sphere_center_x, sphere_bytes);
+	put(o_scy, s.sphere_center_y, sphere_bytes);
+	put(o_scz, s.sphere_center_z, sphere_bytes);
+	put(o_sr, s.sphere_radius, sphere_bytes);
+	put(o_sm, s.sphere_material, sphere_bytes);
+	put(o_pnx, s.plane_normal_x, plane_bytes);
+	put(o_pny, s.plane_normal_y, plane_bytes);
+	put(o_pnz, s.plane_normal_z, plane_bytes);
+	put(o_pd, s.plane_d, plane_bytes);
+	put(o_pm, s.plane_material, plane_bytes);
+	for (uint32_t m = 0; m < s.n_materials; m++)
+	{
+		// attenuation = vec3{ albedo * reflectivity } (mg_ray_tracer.cpp:115,131; colour * float, colour.hpp:144-149)
+		const float refl = s.material_reflectivity[m];
+		const float shading[4] = { s.material_albedo[m * 4 + 0] * refl,
+								   s.material_albedo[m * 4 + 1] * refl,
+								   s.material_albedo[m * 4 + 2] * refl,
+								   s.material_roughness[m] };
+		put(o_shading + m * sizeof(float4), shading, sizeof(shading));
+	}
+	put(o_type, s.material_type, static_cast<size_t>(s.n_materials) * 4);
+
+	RT_HIP_TRY(hipDeviceSynchronize()); // a previous frame may still be reading the old scene
+	RT_HIP_TRY(ctx->scene_columns.reserve(total));
+	RT_HIP_TRY(hipMemcpy(ctx->scene_columns.ptr, host.data(), total, hipMemcpyHostToDevice));
+
+	unsigned char* base = ctx->scene_columns.as<unsigned char>();
+	device_scene& d = ctx->scene;
+	d.n_spheres = s.n_spheres;
+	d.n_planes = s.n_planes;
+	d.n_materials = s.n_materials;
+	d.sphere_cx = reinterpret_cast<const float*>(base + o_scx);
+	d.sphere_cy = reinterpret_cast<const float*>(base + o_scy);
+	d.sphere_cz = reinterpret_cast<const float*>(base + o_scz);
+	d.sphere_r = reinterpret_cast<const float*>(base + o_sr);
+	d.sphere_material = reinterpret_cast<const uint32_t*>(base + o_sm);
+	d.plane_nx = reinterpret_cast<const float*>(base + o_pnx);
+	d.plane_ny = reinterpret_cast<const float*>(base + o_pny);
+	d.plane_nz = reinterpret_cast<const float*>(base + o_pnz);
+	d.plane_d = reinterpret_cast<const float*>(base + o_pd);
+	d.plane_material = reinterpret_cast<const uint32_t*>(base + o_pm);
+	d.material_shading = reinterpret_cast<const float4*>(base + o_shading);
+	d.material_type = reinterpret_cast<const uint32_t*>(base + o_type);
+
+	ctx->samples_per_pixel = s.samples_per_pixel;
+	ctx->max_bounces = s.max_bounces;
+	std::memcpy(ctx->inverse_view_projection, s.inverse_view_projection, sizeof(ctx->inverse_view_projection));
+	ctx->have_scene = true;
+	ctx->stats.upload_ms = static_cast<float>(seconds_since(t0) * 1e3);
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
+											  uint32_t width,
+											  uint32_t height,
+											  uint64_t seed,
+											  uint32_t flags,
+											  const rt_hip_partition* part,
+											  uint32_t* d_rgba8,
+											  float* d_rgb_f32,
+											  void* stream)
+{
+	if (!ctx || !d_rgba8)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: NULL argument");
+	if (!width || !height)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
+	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED))
+		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
+	if (!ctx->have_scene)
+		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
+	const rt_hip_partition whole = { 0, 1, RT_HIP_DEFAULT_STRIPE_ROWS };
+	const rt_hip_partition p = part ? *part : whole;
+	if (!valid_partition(p))
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: invalid partition {rank %u, world %u, stripe_rows %u}", p.rank, p.world, p.stripe_rows);
+
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	const hipStream_t s = static_cast<hipStream_t>(stream);
+
+	frame_params f{};
+	f.width = width;
+	f.height = height;
+	f.local_rows = local_rows_of(height, p.rank, p.world, p.stripe_rows);
+	f.rank = p.rank;
+	f.world = p.world;
+	f.stripe_rows = p.stripe_rows;
+	f.samples_per_pixel = ctx->samples_per_pixel;
+	f.max_bounces = ctx->max_bounces;
+	f.frame_key = frame_key(seed);
+	f.sx = 2.0f / static_cast<float>(width);
+	f.neg_sy = -(2.0f / static_cast<float>(height));
+	const float* M = ctx->inverse_view_projection;
+	for (int r = 0; r < 4; r++)
+	{
+		f.mx[r] = M[r * 4 + 0];
+		f.my[r] = M[r * 4 + 1];
+		f.k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
+		f.k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
+	}
+
+	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
+	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
+	const uint32_t variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_FORCE_TILED) != 0, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	RT_HIP_TRY(hipGetLastError());
+	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
+	ctx->render_recorded = true;
+	ctx->last_stream = s;
+	ctx->stats.kernel_variant = variant;
+	ctx->stats.primary_samples = static_cast<uint64_t>(f.local_rows) * width * f.samples_per_pixel;
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
+												uint32_t width,
+												uint32_t height,
+												uint32_t world,
+												uint32_t stripe_rows,
+												const uint32_t* d_gathered,
+												uint32_t* d_frame,
+												void* stream)
+{
+	if (!ctx || !d_gathered || !d_frame)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_assemble_device: NULL argument");
+	if (!width || !height || !world || !stripe_rows)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_assemble_device: zero size");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	const rt_hip_partition p = { 0, world, stripe_rows };
+	uint32_t padded = 0;
+	if (const rt_hip_status st = rt_hip_padded_local_rows(height, &p, &padded))
+		return st;
+	launch_assemble(width, height, world, stripe_rows, padded, d_gathered, d_frame, static_cast<hipStream_t>(stream));
+	RT_HIP_TRY(hipGetLastError());
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats)
+{
+	if (!ctx || !out_stats)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_stats_fetch: NULL argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	if (ctx->render_recorded)
+	{
+		RT_HIP_TRY(hipEventSynchronize(ctx->render_end));
+		float ms = 0.0f;
+		RT_HIP_TRY(hipEventElapsedTime(&ms, ctx->render_begin, ctx->render_end));
+		ctx->stats.render_ms = ms;
+		device_counters host{};
+		RT_HIP_TRY(hipMemcpy(&host, ctx->counters.ptr, sizeof(host), hipMemcpyDeviceToHost));
+		ctx->stats.segments = host.segments;
+		ctx->stats.sphere_tests = host.segments * ctx->scene.n_spheres;
+		ctx->stats.plane_tests = host.segments * ctx->scene.n_planes;
+	}
+	*out_stats = ctx->stats;
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
+									   const rt_hip_scene* scene,
+									   uint32_t* pixels_rgba8888,
+									   uint32_t width,
+									   uint32_t height,
+									   uint64_t seed,
+									   uint32_t flags,
+									   float* rgb_f32,
+									   rt_hip_stats* stats)
+{
+	if (!ctx || !scene || !pixels_rgba8888)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: NULL argument");
+	if (!width || !height)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: empty frame %ux%u", width, height);
+	if (const rt_hip_status st = rt_hip_scene_upload(ctx, scene))
+		return st;
+	const size_t pixels = static_cast<size_t>(width) * height;
+	RT_HIP_TRY(ctx->frame_rgba.reserve(pixels * sizeof(uint32_t)));
+	if (rgb_f32)
+		RT_HIP_TRY(ctx->frame_rgb.reserve(pixels * 3 * sizeof(float)));
+	if (const rt_hip_status st =
+			rt_hip_render_device(ctx, width, height, seed, flags, nullptr, ctx->frame_rgba.as<uint32_t>(), rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, nullptr))
+		return st;
+	RT_HIP_TRY(hipStreamSynchronize(nullptr));
+	const auto t0 = std::chrono::steady_clock::now();
+	// image_view memory is ordinary pageable host memory (reference src/image.cpp:9-13)
+	RT_HIP_TRY(hipMemcpy(pixels_rgba8888, ctx->frame_rgba.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+	if (rgb_f32)
+		RT_HIP_TRY(hipMemcpy(rgb_f32, ctx->frame_rgb.ptr, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
+	ctx->stats.readback_ms = static_cast<float>(seconds_since(t0) * 1e3);
+	if (stats)
+		return rt_hip_stats_fetch(ctx, stats);
+	return ok();
+}
+
+// ---- known-answer entry points --------------------------------------------------------------------------------------
+
+extern "C" rt_hip_status rt_hip_kat_random(rt_hip_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
+{
+	if (!ctx || !out || !n)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_kat_random: invalid argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	RT_HIP_TRY(ctx->kat_out.reserve(static_cast<size_t>(n) * sizeof(float)));
+	launch_kat_random(frame_key(seed), pixel, sample, n, ctx->kat_out.as<float>(), nullptr);
+	RT_HIP_TRY(hipGetLastError());
+	RT_HIP_TRY(hipMemcpy(out, ctx->kat_out.ptr, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost));
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_kat_closest_hit(rt_hip_ctx* ctx,
+												uint32_t n,
+												const float* origins,
+												const float* directions,
+												float* out_distance,
+												uint32_t* out_kind,
+												uint32_t* out_index,
+												float* out_normal)
+{
+	if (!ctx || !n || !origins || !directions || !out_distance || !out_kind || !out_index || !out_normal)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_kat_closest_hit: invalid argument");
+	if (!ctx->have_scene)
+		return fail(RT_HIP_NO_SCENE, "rt_hip_kat_closest_hit: no scene uploaded");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	const size_t vec_bytes = static_cast<size_t>(n) * 3 * sizeof(float);
+	const size_t scalar_bytes = static_cast<size_t>(n) * sizeof(float);
+	RT_HIP_TRY(ctx->kat_in.reserve(2 * vec_bytes));
+	RT_HIP_TRY(ctx->kat_out.reserve(vec_bytes + 3 * scalar_bytes));
+	unsigned char* in = ctx->kat_in.as<unsigned char>();
+	unsigned char* out = ctx->kat_out.as<unsigned char>();
+	RT_HIP_TRY(hipMemcpy(in, origins, vec_bytes, hipMemcpyHostToDevice));
+	RT_HIP_TRY(hipMemcpy(in + vec_bytes, directions, vec_bytes, hipMemcpyHostToDevice));
+	float* d_distance = reinterpret_cast<float*>(out);
+	uint32_t* d_kind = reinterpret_cast<uint32_t*>(out + scalar_bytes);
+	uint32_t* d_index = reinterpret_cast<uint32_t*>(out + 2 * scalar_bytes);
+	float* d_normal = reinterpret_cast<float*>(out + 3 * scalar_bytes);
+	launch_kat_closest_hit(ctx->scene, n, reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(in + vec_bytes), d_distance, d_kind, d_index, d_normal, nullptr);
+	RT_HIP_TRY(hipGetLastError());
+	RT_HIP_TRY(hipMemcpy(out_distance, d_distance, scalar_bytes, hipMemcpyDeviceToHost));
+	RT_HIP_TRY(hipMemcpy(out_kind, d_kind, scalar_bytes, hipMemcpyDeviceToHost));
+	RT_HIP_TRY(hipMemcpy(out_index, d_index, scalar_bytes, hipMemcpyDeviceToHost));
+	RT_HIP_TRY(hipMemcpy(out_normal, d_normal, vec_bytes, hipMemcpyDeviceToHost));
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div)
+{
+	if (!ctx || !n || !a || !b || !out_sqrt || !out_div)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_kat_sqrt_div: invalid argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	const size_t bytes = static_cast<size_t>(n) * sizeof(float);
+	RT_HIP_TRY(ctx->kat_in.reserve(2 * bytes));
+	RT_HIP_TRY(ctx->kat_out.reserve(2 * bytes));
+	unsigned char* in = ctx->kat_in.as<unsigned char>();
+	unsigned char* out = ctx->kat_out.as<unsigned char>();
+	RT_HIP_TRY(hipMemcpy(in, a, bytes, hipMemcpyHostToDevice));
+	RT_HIP_TRY(hipMemcpy(in + bytes, b, bytes, hipMemcpyHostToDevice));
+	launch_kat_sqrt_div(n, reinterpret_cast<const float*>(in), reinterpret_cast<const float*>(in + bytes), reinterpret_cast<float*>(out), reinterpret_cast<float*>(out + bytes), nullptr);
+	RT_HIP_TRY(hipGetLastError());
+	RT_HIP_TRY(hipMemcpy(out_sqrt, out, bytes, hipMemcpyDeviceToHost));
+	RT_HIP_TRY(hipMemcpy(out_div, out + bytes, bytes, hipMemcpyDeviceToHost));
+	return ok();
+}

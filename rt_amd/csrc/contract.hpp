@@ -1,0 +1,133 @@
+// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v1".
+//
+// Every function here is the gfx950 counterpart of a reference function on the mg_ray_tracer path and produces
+// bit-identical binary32 results to the CPU oracle:
+//   round-to-nearest-even, subnormals kept (hipcc's default f32 mode), no contraction (built with
+//   -ffp-contract=off), fused multiply-adds only where __builtin_fmaf is written, sqrt and '/' correctly
+//   rounded (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt; checked on device by rt_hip_kat_sqrt_div).
+// Comparisons are written in the same (negated) form as the reference so that NaNs take the same branches.
+//
+// Reference citations are relative to the reference root.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rt_hip
+{
+	struct vec3
+	{
+		float x, y, z;
+	};
+
+	__device__ __forceinline__ vec3 operator+(vec3 a, vec3 b) { return { a.x + b.x, a.y + b.y, a.z + b.z }; }
+	__device__ __forceinline__ vec3 operator-(vec3 a, vec3 b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+	__device__ __forceinline__ vec3 operator*(vec3 a, vec3 b) { return { a.x * b.x, a.y * b.y, a.z * b.z }; }
+	__device__ __forceinline__ vec3 operator*(vec3 a, float s) { return { a.x * s, a.y * s, a.z * s }; }
+
+	__device__ __forceinline__ float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+	// dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+	__device__ __forceinline__ float dot(vec3 a, vec3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
+
+	// normalize(v) = v * (1 / sqrt(dot(v,v)))
+	__device__ __forceinline__ vec3 normalize(vec3 v)
+	{
+		const float inv = 1.0f / __builtin_sqrtf(dot(v, v));
+		return v * inv;
+	}
+
+	// muu::ray::at
+	__device__ __forceinline__ vec3 ray_at(vec3 o, vec3 d, float t) { return { fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z) }; }
+
+	// ---- random streams (replaces src/random.cpp:9-26) ------------------------------------
+	__device__ __host__ __forceinline__ uint32_t hash32(uint32_t x)
+	{
+		x ^= x >> 16;
+		x *= 0x7feb352du;
+		x ^= x >> 15;
+		x *= 0x846ca68bu;
+		x ^= x >> 16;
+		return x;
+	}
+
+	__host__ inline uint32_t frame_key(uint64_t seed)
+	{
+		return hash32(static_cast<uint32_t>(seed) ^ hash32(static_cast<uint32_t>(seed >> 32) ^ 0x9E3779B9u));
+	}
+
+	__device__ __forceinline__ uint32_t pixel_key(uint32_t frame, uint32_t pixel_index) { return hash32(frame ^ pixel_index); }
+	__device__ __forceinline__ uint32_t sample_counter(uint32_t pixel, uint32_t sample_index) { return hash32(pixel + sample_index); }
+
+	// random<float>(), src/random.hpp:12-17: uniform in [0, 1)
+	__device__ __forceinline__ float next_random(uint32_t& counter)
+	{
+		counter += 0x9E3779B9u;
+		return static_cast<float>(hash32(counter) >> 8) * 0x1.0p-24f;
+	}
+
+	// random_unit_vector(), src/random.hpp:57-66 (positive octant only)
+	__device__ __forceinline__ vec3 random_unit_vector(uint32_t& counter)
+	{
+		float x, y, z;
+		do
+		{
+			x = next_random(counter);
+			y = next_random(counter);
+			z = next_random(counter);
+		}
+		while (x == 0.0f && y == 0.0f && z == 0.0f);
+		return normalize({ x, y, z });
+	}
+
+	// ---- intersection (muu::ray::hits) --------------------------------------------------------
+	constexpr float min_hit_dist = 0.001f; // mg_ray_tracer.cpp:20
+	constexpr float approx_zero_epsilon = 1.0e-6f;
+
+	// sphere given as (center, radius^2).  true = muu's optional holds a value; t is then the distance.
+	__device__ __forceinline__ bool hits_sphere(vec3 o, vec3 d, vec3 center, float r2, float& t)
+	{
+		const vec3 e = center - o;
+		const float a = dot(e, d);
+		const float e2 = dot(e, e);
+		const float disc = r2 - fma(-a, a, e2);
+		if (disc < 0.0f)
+			return false;
+		const float f = __builtin_sqrtf(disc);
+		t = (e2 < r2) ? a + f : a - f;
+		if (t < 0.0f)
+			return false;
+		return true;
+	}
+
+	__device__ __forceinline__ bool hits_plane(vec3 o, vec3 d, vec3 n, float pd, float& t)
+	{
+		const float den = dot(n, d);
+		if (__builtin_fabsf(den) <= approx_zero_epsilon)
+			return false;
+		const float num = dot(n, o) + pd;
+		t = (-num) / den;
+		if (t < 0.0f)
+			return false;
+		return true;
+	}
+
+	// ---- shading --------------------------------------------------------------------------------------------
+	// mg_ray_tracer.cpp:164
+	__device__ __forceinline__ vec3 sky(float dir_y)
+	{
+		const float t = 0.5f * (dir_y + 1.0f);
+		return { fma(0.5f - 1.0f, t, 1.0f), fma(0.7f - 1.0f, t, 1.0f), fma(1.0f - 1.0f, t, 1.0f) };
+	}
+
+	__device__ __forceinline__ float clamp01(float x) { return x > 1.0f ? 1.0f : (x >= 0.0f ? x : 0.0f); }
+
+	// rt::colour{vec3} -> uint32, src/colour.hpp:63-65,101-106
+	__device__ __forceinline__ uint32_t pack_rgba8888(vec3 c)
+	{
+		const uint32_t r = static_cast<uint32_t>(clamp01(c.x) * 255.99999f);
+		const uint32_t g = static_cast<uint32_t>(clamp01(c.y) * 255.99999f);
+		const uint32_t b = static_cast<uint32_t>(clamp01(c.z) * 255.99999f);
+		return (r << 24u) | (g << 16u) | (b << 8u) | 255u;
+	}
+}

@@ -1,0 +1,132 @@
+// rt_amd/host/host_capi.cpp — see host_capi.h.
+#include "host_capi.h"
+#include "scene.hpp"
+
+#include <exception>
+#include <string>
+
+struct rt_host_scene
+{
+	rt::scene scene;
+};
+
+namespace
+{
+	thread_local std::string g_error;
+
+	template <typename F>
+	rt_host_scene* guarded(F&& make) noexcept
+	{
+		try
+		{
+			g_error.clear();
+			return new rt_host_scene{ make() };
+		}
+		catch (const std::exception& e)
+		{
+			g_error = e.what();
+		}
+		catch (...)
+		{
+			g_error = "unknown error";
+		}
+		return nullptr;
+	}
+}
+
+extern "C" const char* rt_host_last_error(void)
+{
+	return g_error.c_str();
+}
+
+extern "C" rt_host_scene* rt_host_scene_parse(const char* toml_text)
+{
+	return guarded([&] { return rt::scene::parse(toml_text ? toml_text : ""); });
+}
+
+extern "C" rt_host_scene* rt_host_scene_load(const char* path)
+{
+	return guarded([&] { return rt::scene::load(path ? path : ""); });
+}
+
+extern "C" rt_host_scene* rt_host_scene_synthetic(unsigned sphere_count)
+{
+	return guarded([&] { return rt::scene::synthetic(sphere_count); });
+}
+
+extern "C" void rt_host_scene_free(rt_host_scene* scene)
+{
+	delete scene;
+}
+
+extern "C" void rt_host_scene_set_sampling(rt_host_scene* scene, unsigned samples_per_pixel, unsigned max_bounces)
+{
+	if (!scene)
+		return;
+	if (samples_per_pixel)
+		scene->scene.samples_per_pixel = samples_per_pixel;
+	if (max_bounces)
+		scene->scene.max_bounces = max_bounces;
+}
+
+extern "C" void rt_host_scene_set_camera(rt_host_scene* scene, const float position[3], const float direction[3])
+{
+	if (!scene || !position || !direction)
+		return;
+	scene->scene.camera.pose(rt::vec3{ position[0], position[1], position[2] }, rt::vec3{ direction[0], direction[1], direction[2] });
+}
+
+extern "C" int rt_host_scene_describe(const rt_host_scene* scene, unsigned width, unsigned height, rt_hip_scene* out)
+{
+	if (!scene || !out || !width || !height)
+	{
+		g_error = "rt_host_scene_describe: invalid argument";
+		return 1;
+	}
+	const rt::scene& s = scene->scene;
+	static_assert(sizeof(rt::material_type) == sizeof(uint32_t));
+	static_assert(sizeof(rt::colour) == 4 * sizeof(float));
+	static_assert(sizeof(unsigned) == sizeof(uint32_t));
+
+	*out = {};
+	out->n_spheres = static_cast<uint32_t>(s.spheres.size());
+	out->sphere_center_x = s.spheres.center_x();
+	out->sphere_center_y = s.spheres.center_y();
+	out->sphere_center_z = s.spheres.center_z();
+	out->sphere_radius = s.spheres.radius();
+	out->sphere_material = s.spheres.material();
+	out->n_planes = static_cast<uint32_t>(s.planes.size());
+	out->plane_normal_x = s.planes.normal_x();
+	out->plane_normal_y = s.planes.normal_y();
+	out->plane_normal_z = s.planes.normal_z();
+	out->plane_d = s.planes.d();
+	out->plane_material = s.planes.material();
+	out->n_materials = static_cast<uint32_t>(s.materials.size());
+	out->material_type = reinterpret_cast<const uint32_t*>(s.materials.type());
+	out->material_albedo = reinterpret_cast<const float*>(s.materials.albedo());
+	out->material_roughness = s.materials.roughness();
+	out->material_reflectivity = s.materials.reflectivity();
+	out->samples_per_pixel = s.samples_per_pixel;
+	out->max_bounces = s.max_bounces;
+	const rt::viewport view = s.camera.viewport({ width, height });
+	for (size_t r = 0; r < 4; r++)
+		for (size_t c = 0; c < 4; c++)
+			out->inverse_view_projection[r * 4 + c] = view.inverse_view_projection(r, c);
+	return 0;
+}
+
+extern "C" void rt_host_screen_to_world(const rt_host_scene* scene, unsigned width, unsigned height, float x, float y, float depth, float out[3])
+{
+	const rt::viewport view = scene->scene.camera.viewport({ width, height });
+	const rt::vec3 p = view.screen_to_world(x, y, depth);
+	out[0] = p.x, out[1] = p.y, out[2] = p.z;
+}
+
+extern "C" int rt_host_named_colour(const char* name, float out_rgba[4])
+{
+	rt::colour c;
+	if (!name || !rt::named_colour(name, c))
+		return 0;
+	out_rgba[0] = c.r, out_rgba[1] = c.g, out_rgba[2] = c.b, out_rgba[3] = c.a;
+	return 1;
+}

@@ -1,0 +1,133 @@
+"""``HipRayTracer`` — the harness-side handle on one ``rt_hip_ctx`` (one GPU).
+
+Mirrors the lifetime and the call shape of a renderer in the reference: created once
+(``renderers::description::create``, reference src/renderer.hpp:39), asked to ``render(scene, pixels)``
+(src/renderer.hpp:11, src/renderers/mg_ray_tracer.cpp:178), destroyed through ``close()``.
+
+Two ways in, both straight through the C ABI of include/rt_hip.h:
+
+* ``render(scene_pod, width, height, ...)`` -> numpy ``uint32[H, W]`` : the drop-in ``rt_hip_render`` (upload,
+  kernels, copy into a HOST frame) — what the reference-side shim calls.
+* ``upload`` + ``render_device`` (+ ``assemble_device``): the scene stays resident in HBM and frames are
+  written to DEVICE buffers (raw pointers, e.g. of torch tensors) on a caller-chosen stream — what
+  ``bench.py`` and the multi-GPU path use.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import RtHipPartition, RtHipScene, RtHipStats, check
+
+
+def local_rows(height: int, rank: int, world: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS) -> int:
+    out = C.c_uint32()
+    check(capi.hip_lib().rt_hip_local_rows(height, C.byref(RtHipPartition(rank, world, stripe_rows)), C.byref(out)))
+    return out.value
+
+
+def padded_local_rows(height: int, world: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS) -> int:
+    out = C.c_uint32()
+    check(capi.hip_lib().rt_hip_padded_local_rows(height, C.byref(RtHipPartition(0, world, stripe_rows)), C.byref(out)))
+    return out.value
+
+
+def device_count() -> int:
+    n = C.c_int()
+    check(capi.hip_lib().rt_hip_device_count(C.byref(n)))
+    return n.value
+
+
+class HipRayTracer:
+    def __init__(self, device: int = 0):
+        self._lib = capi.hip_lib()
+        self._ctx = C.c_void_p()
+        check(self._lib.rt_hip_create(C.byref(self._ctx), device))
+        self.device = device
+
+    def close(self) -> None:
+        ctx, self._ctx = getattr(self, "_ctx", None), None
+        if ctx:
+            self._lib.rt_hip_destroy(ctx)
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ---- drop-in ------------------------------------------------------------------------------------------
+    def render(self, scene: RtHipScene, width: int, height: int, seed: int = 1, flags: int = 0, want_rgb: bool = False):
+        """rt_hip_render: returns (rgba8 uint32[H, W], rgb float32[H, W, 3] or None, stats dict)."""
+        rgba = np.empty((height, width), dtype=np.uint32)
+        rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
+        stats = RtHipStats()
+        check(
+            self._lib.rt_hip_render(
+                self._ctx,
+                C.byref(scene),
+                rgba.ctypes.data,
+                width,
+                height,
+                seed,
+                flags,
+                rgb.ctypes.data if rgb is not None else None,
+                C.byref(stats),
+            )
+        )
+        return rgba, rgb, stats.as_dict()
+
+    # ---- resident path ------------------------------------------------------------------------------------
+    def upload(self, scene: RtHipScene) -> None:
+        check(self._lib.rt_hip_scene_upload(self._ctx, C.byref(scene)))
+
+    def render_device(
+        self,
+        width: int,
+        height: int,
+        d_rgba8: int,
+        seed: int = 1,
+        flags: int = 0,
+        partition: tuple | None = None,
+        d_rgb_f32: int | None = None,
+        stream: int | None = None,
+    ) -> None:
+        part = C.byref(RtHipPartition(*partition)) if partition is not None else None
+        check(self._lib.rt_hip_render_device(self._ctx, width, height, seed, flags, part, d_rgba8, d_rgb_f32, stream))
+
+    def assemble_device(self, width: int, height: int, world: int, stripe_rows: int, d_gathered: int, d_frame: int, stream: int | None = None) -> None:
+        check(self._lib.rt_hip_assemble_device(self._ctx, width, height, world, stripe_rows, d_gathered, d_frame, stream))
+
+    def stats(self) -> dict:
+        stats = RtHipStats()
+        check(self._lib.rt_hip_stats_fetch(self._ctx, C.byref(stats)))
+        return stats.as_dict()
+
+    # ---- known-answer entry points ------------------------------------------------------------------------
+    def kat_random(self, seed: int, pixel: int, sample: int, n: int) -> np.ndarray:
+        out = np.empty(n, dtype=np.float32)
+        check(self._lib.rt_hip_kat_random(self._ctx, seed, pixel, sample, n, out.ctypes.data))
+        return out
+
+    def kat_closest_hit(self, origins: np.ndarray, directions: np.ndarray):
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        n = len(o)
+        dist = np.empty(n, dtype=np.float32)
+        kind = np.empty(n, dtype=np.uint32)
+        index = np.empty(n, dtype=np.uint32)
+        normal = np.empty((n, 3), dtype=np.float32)
+        check(self._lib.rt_hip_kat_closest_hit(self._ctx, n, o.ctypes.data, d.ctypes.data, dist.ctypes.data, kind.ctypes.data, index.ctypes.data, normal.ctypes.data))
+        return dist, kind, index, normal
+
+    def kat_sqrt_div(self, a: np.ndarray, b: np.ndarray):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        b = np.ascontiguousarray(b, dtype=np.float32)
+        s = np.empty_like(a)
+        q = np.empty_like(a)
+        check(self._lib.rt_hip_kat_sqrt_div(self._ctx, a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data))
+        return s, q
