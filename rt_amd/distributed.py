@@ -1,0 +1,104 @@
+"""Multi-GPU frame rendering: one process per GPU, row-stripe partition, ONE gather to rank 0.
+
+The path shards trivially — every pixel depends only on the scene and its own random stream (the reference
+already exploits this with ``threads.for_range`` over pixel indices, src/renderers/mg_ray_tracer.cpp:203) — so
+there is exactly one exchange step: the per-rank framebuffers are collected on rank 0 (``torch.distributed``
+gather; backend "nccl" is RCCL over xGMI on ROCm) and de-interleaved into the frame.
+
+Partition: stripes of ``stripe_rows`` (8) image rows dealt round-robin to ranks, so that the cheap sky rows and
+the expensive ground rows are spread evenly.  Random streams are keyed by the GLOBAL pixel index, so the
+assembled frame is bit-identical for every world size (tests/test_partition.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import capi
+
+
+def owner_and_local_row(y: int, world: int, stripe_rows: int) -> tuple[int, int]:
+    """(rank that renders image row y, row index inside that rank's compact buffer)."""
+    stripe = y // stripe_rows
+    return stripe % world, (stripe // world) * stripe_rows + y % stripe_rows
+
+
+def local_row_table(height: int, world: int, stripe_rows: int) -> np.ndarray:
+    """int64[height, 2]: (rank, local row) of every image row — the de-interleave map."""
+    table = np.empty((height, 2), dtype=np.int64)
+    for y in range(height):
+        table[y] = owner_and_local_row(y, world, stripe_rows)
+    return table
+
+
+def padded_rows(height: int, world: int, stripe_rows: int) -> int:
+    """Rows of the per-rank buffer used for the equal-sized gather (max over ranks of the rows owned)."""
+    table = local_row_table(height, world, stripe_rows)
+    return int(max((table[table[:, 0] == r, 1].max() + 1) if (table[:, 0] == r).any() else 0 for r in range(world)))
+
+
+def gather_stripes(local: torch.Tensor, dst: int = 0, group=None) -> torch.Tensor | None:
+    """Collect every rank's compact stripe buffer (int32[padded_rows, W]) on `dst`.
+
+    Returns int32[world, padded_rows, W] on `dst`, None elsewhere.  One collective, no ring: each rank's buffer
+    travels once, directly to the root."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if world == 1:
+        return local.unsqueeze(0)
+    if rank == dst:
+        out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.gather(local, gather_list=list(out.unbind(0)), dst=dst, group=group)
+        return out
+    dist.gather(local, gather_list=None, dst=dst, group=group)
+    return None
+
+
+def assemble(gathered: torch.Tensor, width: int, height: int, stripe_rows: int, tracer=None, stream: int | None = None) -> torch.Tensor:
+    """De-interleave int32[world, padded_rows, W] into the int32[H, W] frame.
+
+    Device tensors go through the HIP kernel behind rt_hip_assemble_device and REQUIRE a tracer; host tensors
+    (the gloo rehearsal of the collective in tests) are permuted with torch indexing."""
+    world = gathered.shape[0]
+    if gathered.is_cuda:
+        if tracer is None:
+            raise capi.RtHipError(1, "assemble of device buffers needs the HipRayTracer that owns the GPU")
+        frame = torch.empty((height, width), dtype=gathered.dtype, device=gathered.device)
+        tracer.assemble_device(width, height, world, stripe_rows, gathered.data_ptr(), frame.data_ptr(), stream)
+        return frame
+    table = torch.from_numpy(local_row_table(height, world, stripe_rows))
+    return gathered[table[:, 0], table[:, 1], :width].contiguous()
+
+
+class DistributedFrame:
+    """Per-rank state for rendering frames of one size across the ranks of a process group."""
+
+    def __init__(self, tracer, width: int, height: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS, group=None):
+        self.tracer = tracer
+        self.width, self.height, self.stripe_rows = width, height, stripe_rows
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.padded_rows = padded_rows(height, self.world, stripe_rows)
+        device = torch.device("cuda", tracer.device)
+        self.local = torch.zeros((self.padded_rows, width), dtype=torch.int32, device=device)
+
+    def render(self, seed: int = 1, flags: int = 0) -> torch.Tensor | None:
+        """Render this rank's stripes, gather, assemble.  Returns the int32[H, W] frame on rank 0, else None."""
+        stream = torch.cuda.current_stream().cuda_stream
+        self.tracer.render_device(
+            self.width,
+            self.height,
+            self.local.data_ptr(),
+            seed=seed,
+            flags=flags,
+            partition=(self.rank, self.world, self.stripe_rows),
+            stream=stream,
+        )
+        if self.world == 1:
+            return self.local[: self.height]
+        gathered = gather_stripes(self.local, dst=0, group=self.group)
+        if gathered is None:
+            return None
+        return assemble(gathered, self.width, self.height, self.stripe_rows, tracer=self.tracer, stream=stream)

@@ -1,0 +1,76 @@
+"""The C-ABI library loads and exports every symbol include/rt_hip.h declares; its host-only helpers and its
+error behaviour work without a GPU.  No compute calls here."""
+import ctypes as C
+import re
+
+import numpy as np
+import pytest
+
+import rt_amd
+from rt_amd import capi
+from tests.conftest import ROOT
+
+
+def declared_functions(header_text: str):
+    text = re.sub(r"/\*.*?\*/", "", header_text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_hip_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_all_exported():
+    names = declared_functions((ROOT / "include" / "rt_hip.h").read_text())
+    assert len(names) >= 15
+    lib = C.CDLL(str(capi.hip_library_path()))
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/rt_hip.h but not exported"
+    bound = {name for name, _, _ in capi.RT_HIP_SYMBOLS}
+    assert bound == set(names), f"bindings and header disagree: {bound ^ set(names)}"
+
+
+def test_abi_version_and_struct_sizes():
+    assert capi.hip_lib().rt_hip_abi_version() == 1
+    # LP64 layout of the PODs in include/rt_hip.h
+    assert C.sizeof(capi.RtHipPartition) == 12
+    assert C.sizeof(capi.RtHipScene) == 8 * 6 + 8 * 6 + 8 * 5 + 8 + 64
+    assert C.sizeof(capi.RtHipStats) == 4 * 8 + 4 * 4
+
+
+def test_last_error_never_null():
+    assert capi.hip_lib().rt_hip_last_error() is not None
+
+
+def test_null_arguments_are_refused_not_crashed():
+    lib = capi.hip_lib()
+    assert lib.rt_hip_create(None, 0) == 1
+    assert b"NULL" in lib.rt_hip_last_error()
+    assert lib.rt_hip_device_count(None) == 1
+    assert lib.rt_hip_scene_upload(None, None) == 1
+    assert lib.rt_hip_render(None, None, None, 4, 4, 0, 0, None, None) == 1
+    assert lib.rt_hip_stats_fetch(None, None) == 1
+    lib.rt_hip_destroy(None)  # no-op
+
+
+@pytest.mark.parametrize(
+    "height,world,stripe",
+    [(1080, 1, 8), (1080, 2, 8), (1080, 4, 8), (1080, 8, 8), (2160, 8, 8), (7, 2, 8), (17, 3, 4), (1, 8, 8), (100, 8, 16), (33, 5, 1)],
+)
+def test_partition_rows_cover_the_frame(height, world, stripe):
+    from rt_amd import distributed
+
+    rows = [rt_amd.local_rows(height, r, world, stripe) for r in range(world)]
+    assert sum(rows) == height
+    assert rt_amd.padded_local_rows(height, world, stripe) == max(rows)
+    assert distributed.padded_rows(height, world, stripe) == max(rows)
+    table = distributed.local_row_table(height, world, stripe)
+    for r in range(world):
+        local = table[table[:, 0] == r, 1]
+        assert len(local) == rows[r]
+        assert np.array_equal(np.sort(local), np.arange(rows[r]))  # compact, each local row used once
+
+
+def test_partition_rejects_bad_arguments():
+    with pytest.raises(rt_amd.RtHipError):
+        rt_amd.local_rows(10, 2, 2, 8)  # rank >= world
+    with pytest.raises(rt_amd.RtHipError):
+        rt_amd.local_rows(10, 0, 0, 8)
+    with pytest.raises(rt_amd.RtHipError):
+        rt_amd.padded_local_rows(10, 2, 0)

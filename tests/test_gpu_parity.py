@@ -1,0 +1,301 @@
+"""Parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+The bar is BIT-EXACT — on the packed RGBA8888 frame AND on the float32 per-pixel mean before the gamma — because
+both sides implement the same arithmetic contract: identical IEEE binary32 operations in
+identical order.  Tolerance: 0 ulp.  Where a frame is too big for the oracle to finish in seconds, a stripe
+subset of it is checked bit-for-bit and the rest through size-independent properties (partition invariance,
+segment-count bookkeeping, opaque alpha).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import rt_amd
+from oracle import binding as oracle
+from rt_amd import capi
+from tests.conftest import GOLDEN, unpack
+
+pytestmark = pytest.mark.gpu
+
+FORCE_TILED = capi.RT_HIP_FLAG_FORCE_TILED
+
+
+def assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, what=""):
+    float_equal = np.array_equal(got_rgb.view(np.uint32), want_rgb.view(np.uint32))
+    if not float_equal:
+        bad = (got_rgb.view(np.uint32) != want_rgb.view(np.uint32)).any(axis=-1)
+        ys, xs = np.nonzero(bad)
+        raise AssertionError(
+            f"{what}: float32 mean differs in {bad.sum()} of {bad.size} pixels; first at (x={xs[0]}, y={ys[0]}): "
+            f"gpu {got_rgb[ys[0], xs[0]]} vs oracle {want_rgb[ys[0], xs[0]]}"
+        )
+    assert np.array_equal(got_rgba, want_rgba), f"{what}: RGBA8 differs in {(got_rgba != want_rgba).sum()} pixels"
+
+
+# ---- leaf functions ----------------------------------------------------------------------------------------------------
+def test_device_sqrt_and_division_are_correctly_rounded(tracer):
+    rng = np.random.default_rng(0)
+    n = 1 << 20
+    # random bit patterns cover normals, subnormals, zeros, infinities and NaNs
+    a = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    b = rng.integers(0, 1 << 32, n, dtype=np.uint64).astype(np.uint32).view(np.float32)
+    # plus the ranges the renderer actually uses
+    a[: n // 4] = np.abs(rng.normal(size=n // 4)).astype(np.float32) * np.float32(10) ** rng.integers(-8, 8, n // 4).astype(np.float32)
+    b[: n // 4] = rng.normal(size=n // 4).astype(np.float32)
+    a[n // 4 : n // 4 + 8] = [0.0, -0.0, 1.0, np.inf, 1e-45, 1.1754944e-38, 3.4028235e38, 2.0]
+    b[n // 4 : n // 4 + 8] = [0.0, 1.0, 3.0, np.inf, 7.0, 3.0, 1e-45, -0.0]
+    gs, gq = tracer.kat_sqrt_div(a, b)
+    with np.errstate(all="ignore"):
+        ws, wq = oracle.sqrt_div(a, b)
+
+    def same(x, y):  # bitwise, except that any NaN matches any NaN
+        return (x.view(np.uint32) == y.view(np.uint32)) | (np.isnan(x) & np.isnan(y))
+
+    assert same(gs, ws).all(), f"sqrt differs at {np.nonzero(~same(gs, ws))[0][:5]}"
+    assert same(gq, wq).all(), f"division differs at {np.nonzero(~same(gq, wq))[0][:5]}"
+
+
+@pytest.mark.parametrize("seed,pixel,sample", [(1, 0, 0), (1, 12345, 7), (0xDEADBEEFCAFE, 2073599, 255), (2**64 - 1, 2**32 - 1, 999)])
+def test_device_random_stream_equals_oracle(tracer, seed, pixel, sample):
+    got = tracer.kat_random(seed, pixel, sample, 4096)
+    want = oracle.random(seed, pixel, sample, 4096)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_random_stream_golden_vector(tracer):
+    golden = np.load(GOLDEN / "random_stream.npz")
+    got = tracer.kat_random(int(golden["seed"]), int(golden["pixel"]), int(golden["sample"]), len(golden["draws"]))
+    assert np.array_equal(got.view(np.uint32), golden["draws"].view(np.uint32))
+
+
+def rays_for(scene_pod, width, height, n, rng):
+    """Primary rays plus random secondary-like rays starting near surfaces."""
+    origins, dirs = [], []
+    for _ in range(n // 2):
+        o, d = oracle.primary_ray(scene_pod, width, height, rng.uniform(0, width), rng.uniform(0, height))
+        origins.append(o), dirs.append(d)
+    o = rng.uniform(-3, 3, (n - n // 2, 3)).astype(np.float32)
+    o[:, 1] = np.abs(o[:, 1])
+    d = rng.normal(size=(n - n // 2, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return np.concatenate([np.array(origins), o]).astype(np.float32), np.concatenate([np.array(dirs), d]).astype(np.float32)
+
+
+@pytest.mark.parametrize("name", ["basic", "dielectric", "planes", "synthetic-3000"])
+def test_device_closest_hit_equals_oracle(tracer, planes_scene, name):
+    scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
+    pod = scene.describe(160, 90)
+    tracer.upload(pod)
+    origins, dirs = rays_for(pod, 160, 90, 3000, np.random.default_rng(3))
+    got = tracer.kat_closest_hit(origins, dirs)
+    want = oracle.closest_hit(pod, origins, dirs)
+    for g, w, label in zip(got, want, ("distance", "kind", "index", "normal")):
+        assert np.array_equal(g.view(np.uint32), w.view(np.uint32)), f"{name}: closest-hit {label} differs"
+    assert (want[1] != 0).mean() > 0.2  # the vectors do exercise hits
+
+
+def test_device_closest_hit_tie_breaks(tracer):
+    mat = [(0, 1, 1, 1, 1, 0.5, 0.5)]
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 0), (0, 0, -5, 1, 0)], planes=[(0, 0, 1, 4, 0)], materials=mat)
+    tracer.upload(pod)
+    dist, kind, index, normal = tracer.kat_closest_hit([(0, 0, 0)], [(0, 0, -1)])
+    assert dist[0] == 4.0 and kind[0] == 1 and index[0] == 0  # lowest sphere index; sphere beats plane at equal t
+    assert np.array_equal(normal[0], np.array([0, 0, 1], dtype=np.float32))
+
+
+# ---- frames: small enough for the oracle to render whole ------------------------------------------------------------------
+CASES = [
+    # name, width, height, spp, max_bounces, seed
+    ("basic", 256, 256, 1, 10, 1),  # BASELINE config 1
+    ("basic", 160, 90, 16, 10, 2),
+    ("basic", 67, 33, 5, 3, 3),  # ragged: not a multiple of the 32x8 workgroup tile
+    ("basic", 1, 1, 2, 10, 4),
+    ("basic", 5, 70, 3, 1, 5),  # max_bounces = 1: every hit is black
+    ("dielectric", 192, 108, 8, 10, 6),  # BASELINE config 3's scene (attenuation > 1, metal, 7 materials)
+    ("dielectric", 64, 36, 32, 1000, 7),  # bounce limit far above any path length
+    ("planes", 128, 72, 8, 6, 8),  # planes + spheres + metal + a box entry that mg ignores
+    ("synthetic-1000", 96, 54, 2, 10, 9),  # resident kernel at its LDS capacity (1000 <= 1024 primitives)
+    ("synthetic-2500", 64, 36, 2, 10, 10),  # tiled kernel: 3 LDS tiles, ragged last tile
+]
+
+
+@pytest.mark.parametrize("name,width,height,spp,bounces,seed", CASES)
+@pytest.mark.parametrize("flags", [0, FORCE_TILED], ids=["auto", "tiled"])
+def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, bounces, seed, flags):
+    scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
+    scene.set_sampling(spp, bounces)
+    pod = scene.describe(width, height)
+    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{name} {width}x{height}x{spp} ({stats['kernel']})")
+    assert stats["segments"] == want_stats["segments"]
+    assert stats["primary_samples"] == width * height * spp
+    assert stats["sphere_tests"] == want_stats["segments"] * pod.n_spheres
+    expected_kernel = "tiled" if (flags or pod.n_spheres + pod.n_planes > 1024) else "resident"
+    assert stats["kernel"] == expected_kernel
+
+
+def test_empty_scene_renders_sky(tracer):
+    ivp = rt_amd.Scene.named("basic").describe(40, 24).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(samples_per_pixel=3, max_bounces=2, inverse_view_projection=ivp)
+    for flags in (0, FORCE_TILED):
+        got_rgba, got_rgb, stats = tracer.render(pod, 40, 24, seed=1, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, _ = oracle.render(pod, 40, 24, seed=1)
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "empty scene")
+        assert stats["segments"] == 40 * 24 * 3
+
+
+def test_seed_changes_the_image_and_equal_seeds_repeat_it(tracer):
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    pod = scene.describe(96, 54)
+    a, _, _ = tracer.render(pod, 96, 54, seed=1)
+    b, _, _ = tracer.render(pod, 96, 54, seed=1)
+    c, _, _ = tracer.render(pod, 96, 54, seed=2)
+    assert np.array_equal(a, b) and not np.array_equal(a, c)
+
+
+# ---- golden fixtures (committed; made by tools/gen_golden.py from the oracle) ---------------------------------------------
+@pytest.mark.parametrize("fixture", ["basic_64x36_spp4", "dielectric_64x36_spp4", "planes_48x27_spp4", "synthetic1500_32x18_spp2"])
+def test_frame_matches_committed_golden(tracer, planes_scene, fixture):
+    golden = np.load(GOLDEN / f"{fixture}.npz")
+    name = str(golden["scene"])
+    scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
+    scene.set_sampling(int(golden["spp"]), int(golden["max_bounces"]))
+    width, height = int(golden["width"]), int(golden["height"])
+    got_rgba, got_rgb, _ = tracer.render(scene.describe(width, height), width, height, seed=int(golden["seed"]), want_rgb=True)
+    assert_bit_exact(got_rgba, got_rgb, golden["rgba"], golden["rgb"], fixture)
+
+
+# ---- multi-GPU partition on one GPU: every rank's stripes, assembled on the device ----------------------------------------
+@pytest.mark.parametrize("world,stripe", [(2, 8), (4, 8), (8, 8), (3, 5), (8, 16)])
+def test_partition_invariance_and_device_assemble(tracer, world, stripe):
+    import torch
+
+    width, height = 200, 117  # ragged in both directions
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    pod = scene.describe(width, height)
+    whole, _, whole_stats = tracer.render(pod, width, height, seed=5)
+    tracer.upload(pod)
+    padded = rt_amd.padded_local_rows(height, world, stripe)
+    gathered = torch.zeros((world, padded, width), dtype=torch.int32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    segments = 0
+    for rank in range(world):
+        tracer.render_device(width, height, gathered[rank].data_ptr(), seed=5, partition=(rank, world, stripe), stream=stream)
+        segments += tracer.stats()["segments"]
+        part, _, _ = oracle.render(pod, width, height, seed=5, partition=(rank, world, stripe), want_rgb=False)
+        torch.cuda.synchronize()
+        got = gathered[rank].cpu().numpy().view(np.uint32)[: part.shape[0]]
+        assert np.array_equal(got, part), f"rank {rank}/{world} stripes differ from the oracle's"
+    frame = torch.empty((height, width), dtype=torch.int32, device="cuda:0")
+    tracer.assemble_device(width, height, world, stripe, gathered.data_ptr(), frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().view(np.uint32), whole)
+    assert segments == whole_stats["segments"]
+
+
+# ---- BASELINE.json's full sizes -----------------------------------------------------------------------------------------------
+def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
+    """Render the full frame on the GPU; bit-check one stripe subset (rank 0 of `oracle_world`) against the oracle;
+    check the rest through properties."""
+    import torch
+
+    pod = scene.describe(width, height)
+    tracer.upload(pod)
+    frame = torch.empty((height, width), dtype=torch.int32, device="cuda:0")
+    mean = torch.empty((height, width, 3), dtype=torch.float32, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    tracer.render_device(width, height, frame.data_ptr(), seed=seed, flags=flags, d_rgb_f32=mean.data_ptr(), stream=stream)
+    stats = tracer.stats()
+    rgba = frame.cpu().numpy().view(np.uint32)
+    rgb = mean.cpu().numpy()
+    # oracle: rank 0's stripes of an `oracle_world`-way partition (every oracle_world-th stripe of 8 rows)
+    want_rgba, want_rgb, _ = oracle.render(pod, width, height, seed=seed, partition=(0, oracle_world, 8))
+    from rt_amd import distributed
+
+    table = distributed.local_row_table(height, oracle_world, 8)
+    rows = np.nonzero(table[:, 0] == 0)[0]
+    assert_bit_exact(rgba[rows], rgb[rows], want_rgba, want_rgb, f"{width}x{height} stripe subset")
+    # properties over the whole frame
+    assert np.all((rgba & 0xFF) == 0xFF)  # opaque alpha everywhere (colour.hpp:63-65)
+    assert np.isfinite(rgb).all() and (rgb >= 0).all()
+    spp = pod.samples_per_pixel
+    assert stats["primary_samples"] == width * height * spp
+    assert width * height * spp <= stats["segments"] <= width * height * spp * pod.max_bounces
+    # the frame equals its own 8-way partition (what the 8-GPU run computes), checked on the device
+    padded = rt_amd.padded_local_rows(height, 8, 8)
+    gathered = torch.zeros((8, padded, width), dtype=torch.int32, device="cuda:0")
+    for rank in range(8):
+        tracer.render_device(width, height, gathered[rank].data_ptr(), seed=seed, flags=flags, partition=(rank, 8, 8), stream=stream)
+    again = torch.empty_like(frame)
+    tracer.assemble_device(width, height, 8, 8, gathered.data_ptr(), again.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert torch.equal(again, frame)
+    return stats
+
+
+def test_config2_basic_1080p_64spp(tracer):
+    """BASELINE config 2 at full size; the oracle covers 1/8 of the rows (every 8th stripe)."""
+    stats = check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(64), 1920, 1080, seed=1, oracle_world=8)
+    assert stats["kernel"] == "resident"
+
+
+def test_config3_dielectric_1080p_256spp(tracer):
+    """BASELINE config 3 at full size (mg semantics: dielectrics shade as lambert); the oracle covers 1/32 of the rows."""
+    check_full_size(tracer, rt_amd.Scene.named("dielectric").set_sampling(256), 1920, 1080, seed=1, oracle_world=32)
+
+
+def test_headline_basic_1080p_256spp(tracer):
+    """The headline workload of bench.py; the oracle covers 1/32 of the rows."""
+    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(256), 1920, 1080, seed=1, oracle_world=32)
+
+
+def test_config4_basic_4k_tile_split(tracer):
+    """BASELINE config 4's frame (3840x2160) at reduced spp: every rank's part of the 8-way split, assembled."""
+    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(8), 3840, 2160, seed=1, oracle_world=16)
+
+
+def test_config5_synthetic_100k_tiled(tracer):
+    """BASELINE config 5's scene (100 000 spheres, LDS-tiled kernel) at a size the oracle finishes in seconds,
+    bit-exact; the full 1920x1080x64 frame is a bench configuration (minutes of oracle time per stripe)."""
+    scene = rt_amd.Scene.named("synthetic-100k").set_sampling(1)
+    width, height = 64, 36
+    pod = scene.describe(width, height)
+    assert pod.n_spheres == 100000
+    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=1, want_rgb=True)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=1)
+    assert stats["kernel"] == "tiled"
+    assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "synthetic-100k")
+    assert stats["segments"] == want_stats["segments"]
+
+
+# ---- error behaviour of the boundary -----------------------------------------------------------------------------------------------
+def test_render_before_upload_is_refused():
+    with rt_amd.HipRayTracer(0) as fresh:
+        with pytest.raises(rt_amd.RtHipError) as err:
+            fresh.render_device(8, 8, 0x1000)
+        assert err.value.status == 4  # RT_HIP_NO_SCENE
+
+
+def test_bad_arguments_are_refused(tracer):
+    pod = rt_amd.Scene.named("basic").describe(16, 16)
+    with pytest.raises(rt_amd.RtHipError) as err:
+        tracer.render(pod, 16, 16, flags=0x8000)
+    assert err.value.status == 5  # RT_HIP_UNSUPPORTED
+    with pytest.raises(rt_amd.RtHipError) as err:
+        tracer.render(pod, 0, 16)
+    assert err.value.status == 1
+    bad = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 3)], materials=[(0, 1, 1, 1, 1, 0.5, 0.5)])
+    with pytest.raises(rt_amd.RtHipError) as err:
+        tracer.upload(bad)
+    assert err.value.status == 1 and "out-of-range" in str(err.value)
+    zero_spp = rt_amd.scene_from_arrays(samples_per_pixel=0)
+    with pytest.raises(rt_amd.RtHipError):
+        tracer.upload(zero_spp)
+    with pytest.raises(rt_amd.RtHipError) as err:
+        rt_amd.HipRayTracer(device=99)
+    assert err.value.status == 2  # RT_HIP_NO_DEVICE
+    # the context is still usable after refused calls
+    rgba, _, _ = tracer.render(pod, 16, 16)
+    assert rgba.shape == (16, 16)

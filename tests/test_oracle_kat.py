@@ -1,0 +1,309 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference ships no tests or golden vectors ("parity unpinned"), so every expectation here is
+derived from the reference's SOURCE and computed independently of the oracle's code (closed forms, float64 numpy).
+"""
+import math
+
+import numpy as np
+import pytest
+
+import rt_amd
+from oracle import binding as oracle
+from tests.conftest import unpack
+
+BLACK = 0x000000FF
+
+
+# ---- colour pack: reference src/colour.hpp:101-106 (clamp to [0,1], x 255.99999f, truncate, RGBA8888) --------------
+@pytest.mark.parametrize(
+    "rgb,expected",
+    [
+        ((1.0, 0.0, 1.0), 0xFF00FFFF),
+        ((0.25, 0.25, 0.25), 0x3F3F3FFF),  # 0.25 * 255.99999 = 63.99 -> 63
+        ((0.5, 0.5, 0.5), 0x7F7F7FFF),
+        ((2.0, -1.0, 0.999999), 0xFF00FFFF),
+        ((0.0, 1.0 / 255.99999, 0.00390626), 0x000001FF),
+        ((float("nan"), 0.0, 0.0), 0x000000FF),
+    ],
+)
+def test_pack(rgb, expected):
+    assert oracle.pack(*rgb) == expected
+
+
+def test_pack_matches_closed_form_everywhere():
+    xs = np.linspace(-0.5, 1.5, 4001, dtype=np.float32)
+    for x in xs[::7]:
+        want = int(np.float32(min(max(x, np.float32(0)), np.float32(1))) * np.float32(255.99999))
+        assert (oracle.pack(float(x), 0.0, 0.0) >> 24) == want
+
+
+# ---- sky: reference mg_ray_tracer.cpp:164 ------------------------------------------------------------------------
+@pytest.mark.parametrize("dir_y", [-1.0, -0.3, 0.0, 0.123, 1.0])
+def test_sky(dir_y):
+    t = 0.5 * (dir_y + 1.0)
+    want = np.array([1.0 + (0.5 - 1.0) * t, 1.0 + (0.7 - 1.0) * t, 1.0])
+    assert np.allclose(oracle.sky(dir_y), want, rtol=0, atol=2e-7)
+
+
+# ---- camera: reference src/camera.hpp:42-48,122-137 with the conventions of SURVEY.md §8c(4,5) -------------------
+def analytic_primary_direction(px, py, width, height, eye_dir=(0.0, 0.0, -1.0)):
+    """Direction through screen position (px, py) for a camera looking down eye_dir with +Y up, vfov pi/4."""
+    f = np.array(eye_dir, dtype=np.float64)
+    f /= np.linalg.norm(f)
+    r = np.cross(f, [0.0, 1.0, 0.0])
+    r /= np.linalg.norm(r)
+    u = np.cross(r, f)
+    tan_half = math.tan(math.pi / 8)
+    ndc_x = 2.0 * px / width - 1.0
+    ndc_y = 1.0 - 2.0 * py / height
+    d = f + r * (ndc_x * tan_half * width / height) + u * (ndc_y * tan_half)
+    return d / np.linalg.norm(d)
+
+
+@pytest.mark.parametrize("size", [(256, 256), (1920, 1080), (64, 36), (7, 3)])
+def test_primary_rays_match_pinhole_model(size):
+    width, height = size
+    scene = rt_amd.Scene.named("basic")
+    pod = scene.describe(width, height)
+    eye = np.array([0.0, 1.0, 3.0])
+    for px, py in [(width / 2, height / 2), (0.0, 0.0), (width, height), (0.5, height - 0.5), (width * 0.25, height * 0.9)]:
+        o, d = oracle.primary_ray(pod, width, height, px, py)
+        want = analytic_primary_direction(px, py, width, height)
+        # float32 inverse view-projection with near 0.01 / far 1000: ~1e-5 rad of direction error
+        assert np.allclose(d, want, atol=5e-5), (px, py, d, want)
+        # origin lies on the same eye ray, close to the eye (near plane 0.01)
+        off = o.astype(np.float64) - eye
+        assert 0.005 < np.linalg.norm(off) < 0.03
+        assert np.allclose(off / np.linalg.norm(off), want, atol=2e-3)
+
+
+def test_primary_ray_for_rotated_camera():
+    scene = rt_amd.Scene.named("basic").set_camera((1.0, 2.0, 3.0), (0.3, -0.2, -1.0))
+    pod = scene.describe(320, 200)
+    for px, py in [(160.0, 100.0), (10.5, 20.5), (300.0, 190.0)]:
+        _, d = oracle.primary_ray(pod, 320, 200, px, py)
+        assert np.allclose(d, analytic_primary_direction(px, py, 320, 200, (0.3, -0.2, -1.0)), atol=5e-5)
+
+
+# ---- visibility mask: max_bounces = 1 -> hit pixels are exactly black, miss pixels are the sky --------------------
+def analytic_visibility(width, height, eye, spheres):
+    """float64 closest-hit of the pixel-centre rays: (hit mask, |distance to silhouette| proxy, dir_y)."""
+    ys, xs = np.mgrid[0:height, 0:width]
+    px, py = xs + 0.5, ys + 0.5
+    tan_half = math.tan(math.pi / 8)
+    dx = (2.0 * px / width - 1.0) * tan_half * width / height
+    dy = (1.0 - 2.0 * py / height) * tan_half
+    d = np.stack([dx, dy, -np.ones_like(dx)], axis=-1)
+    d /= np.linalg.norm(d, axis=-1, keepdims=True)
+    hit = np.zeros((height, width), dtype=bool)
+    margin = np.full((height, width), np.inf)
+    for cx, cy, cz, r in spheres:
+        e = np.array([cx, cy, cz]) - eye
+        a = d @ e
+        disc = r * r - (e @ e - a * a)
+        hit |= (disc >= 0) & (a - np.sqrt(np.maximum(disc, 0)) >= 0.001)
+        margin = np.minimum(margin, np.abs(disc) / (2 * r))  # ~ distance between ray and sphere surface
+    return hit, margin, d[..., 1]
+
+
+@pytest.mark.parametrize("name,eye", [("basic", (0.0, 1.0, 3.0)), ("dielectric", (0.0, 1.0, 7.0))])
+def test_visibility_mask_against_analytic_silhouettes(name, eye):
+    width, height = 160, 90
+    scene = rt_amd.Scene.named(name).set_sampling(samples_per_pixel=1, max_bounces=1)
+    pod = scene.describe(width, height)
+    rgba, rgb, stats = oracle.render(pod, width, height, seed=3)
+    spheres = [(pod.sphere_center_x[i], pod.sphere_center_y[i], pod.sphere_center_z[i], pod.sphere_radius[i]) for i in range(pod.n_spheres)]
+    hit, margin, dir_y = analytic_visibility(width, height, np.array(eye), spheres)
+    safe = margin > 2e-3  # stay clear of silhouette edges, where float32 may flip hit/miss
+    assert safe.mean() > 0.9
+    # hit pixels: attenuation * trace(..., 0) = attenuation * 0 -> black (mg_ray_tracer.cpp:157-158,171)
+    assert np.all(rgba[hit & safe] == BLACK)
+    # miss pixels: pack(sqrt(sky(dir.y))) (mg_ray_tracer.cpp:163-164,196-200)
+    t = 0.5 * (dir_y + 1.0)
+    sky = np.stack([1.0 - 0.5 * t, 1.0 - 0.3 * t, np.ones_like(t)], axis=-1)
+    want = np.floor(np.sqrt(sky) * 255.99999).astype(np.int64)
+    got = unpack(rgba)[..., :3].astype(np.int64)
+    miss = ~hit & safe
+    assert miss.sum() > 1000
+    assert np.abs(got[miss] - want[miss]).max() <= 1  # float32 vs float64 rounding at a quantisation step
+    assert (got[miss] != want[miss]).mean() < 0.01
+    assert np.all(unpack(rgba)[..., 3] == 255)
+    assert stats["segments"] == width * height  # exactly one closest-hit query per sample
+
+
+# ---- closest hit: formulas of SURVEY.md §8c(1,2), scan order of mg_ray_tracer.cpp:36-102 -------------------------
+MAT = [(0, 1, 1, 1, 1, 0.5, 0.5)]
+
+
+def test_tie_break_lowest_sphere_index_wins():
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 0), (0, 0, -5, 1, 0), (0, 0, -9, 1, 0)], materials=MAT)
+    dist, kind, index, normal = oracle.closest_hit(pod, [(0, 0, 0)], [(0, 0, -1)])
+    assert kind[0] == 1 and index[0] == 0 and dist[0] == pytest.approx(4.0, abs=1e-6)
+    assert np.allclose(normal[0], (0, 0, 1), atol=1e-6)
+
+
+def test_tie_break_sphere_beats_plane_at_equal_distance():
+    # plane z = -4 (normal +z, d = 4) touches the near pole of the sphere: both are hit at t = 4 exactly
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 0)], planes=[(0, 0, 1, 4, 0)], materials=MAT)
+    dist, kind, index, _ = oracle.closest_hit(pod, [(0, 0, 0)], [(0, 0, -1)])
+    assert dist[0] == 4.0 and kind[0] == 1
+    # ...and the plane wins as soon as it is strictly closer
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 0)], planes=[(0, 0, 1, 3.5, 0)], materials=MAT)
+    dist, kind, index, normal = oracle.closest_hit(pod, [(0, 0, 0)], [(0, 0, -1)])
+    assert dist[0] == 3.5 and kind[0] == 2 and np.array_equal(normal[0], (0, 0, 1))
+
+
+def test_hits_behind_or_too_close_are_rejected():
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, 5, 1, 0)], planes=[(0, 1, 0, 1, 0)], materials=MAT)
+    # sphere behind the ray, plane y = -1 behind an upward ray
+    dist, kind, _, _ = oracle.closest_hit(pod, [(0, 0, 0)], [(0, 0.6, -0.8)])
+    assert kind[0] == 0 and dist[0] < 0
+    # min_hit_dist = 0.001 (mg_ray_tracer.cpp:20): origin 0.0005 above the plane, looking down -> rejected
+    dist, kind, _, _ = oracle.closest_hit(pod, [(0, -0.9995, 0)], [(0, -1, 0)])
+    assert kind[0] == 0
+    dist, kind, _, _ = oracle.closest_hit(pod, [(0, -0.99, 0)], [(0, -1, 0)])
+    assert kind[0] == 2 and dist[0] == pytest.approx(0.01, rel=1e-4)
+
+
+def test_ray_from_inside_a_sphere_hits_the_far_side():
+    pod = rt_amd.scene_from_arrays(spheres=[(0, 0, 0, 2, 0)], materials=MAT)
+    dist, kind, _, normal = oracle.closest_hit(pod, [(0.5, 0, 0)], [(1, 0, 0)])
+    assert kind[0] == 1 and dist[0] == pytest.approx(1.5, abs=1e-6)
+    assert np.allclose(normal[0], (1, 0, 0), atol=1e-6)  # outward normal, not flipped toward the ray
+
+
+def test_parallel_ray_misses_plane():
+    pod = rt_amd.scene_from_arrays(planes=[(0, 1, 0, 0, 0)], materials=MAT)
+    _, kind, _, _ = oracle.closest_hit(pod, [(0, 1, 0)], [(1, 0, 0)])
+    assert kind[0] == 0
+
+
+def test_closest_hit_against_float64_brute_force():
+    rng = np.random.default_rng(5)
+    n_s = 40
+    spheres = np.column_stack([rng.uniform(-5, 5, n_s), rng.uniform(-5, 5, n_s), rng.uniform(-15, -5, n_s), rng.uniform(0.2, 1.0, n_s), np.zeros(n_s)])
+    pod = rt_amd.scene_from_arrays(spheres=spheres, materials=MAT)
+    origins = rng.uniform(-1, 1, (3000, 3))
+    dirs = rng.normal(size=(3000, 3)) * [0.4, 0.4, 0.1] + [0, 0, -1]
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    dist, kind, index, _ = oracle.closest_hit(pod, origins, dirs)
+    o32, d32 = origins.astype(np.float32).astype(np.float64), dirs.astype(np.float32).astype(np.float64)
+    s32 = spheres.astype(np.float32).astype(np.float64)
+    e = s32[None, :, :3] - o32[:, None, :]
+    a = np.einsum("nsk,nk->ns", e, d32)
+    disc = s32[None, :, 3] ** 2 - (np.einsum("nsk,nsk->ns", e, e) - a * a)
+    t = np.where(disc >= 0, a - np.sqrt(np.maximum(disc, 0)), np.inf)
+    t[t < 0.001] = np.inf
+    best = t.argmin(axis=1)
+    best_t = t.min(axis=1)
+    clear = np.abs(disc).min(axis=1) > 1e-3  # rays grazing a sphere may legitimately differ in float32
+    hit = np.isfinite(best_t)
+    assert np.array_equal(kind[clear] == 1, hit[clear])
+    sel = clear & hit
+    assert sel.sum() > 300
+    assert np.array_equal(index[sel], best[sel])
+    assert np.allclose(dist[sel], best_t[sel], rtol=1e-4)
+
+
+# ---- random streams ---------------------------------------------------------------------------------------------------
+def test_random_stream_is_uniform_and_deterministic():
+    u = oracle.random(seed=1, pixel=12345, sample=7, n=200000)
+    assert u.dtype == np.float32 and u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 0.003 and abs(u.var() - 1 / 12) < 0.002
+    counts, _ = np.histogram(u, bins=64, range=(0, 1))
+    chi2 = ((counts - len(u) / 64) ** 2 / (len(u) / 64)).sum()
+    assert chi2 < 120  # 63 dof; p ~ 1e-5
+    assert abs(np.corrcoef(u[:-1], u[1:])[0, 1]) < 0.01
+    assert np.array_equal(u[:100], oracle.random(1, 12345, 7, 100))
+
+
+def test_random_streams_of_neighbouring_pixels_and_samples_are_unrelated():
+    base = oracle.random(1, 1000, 3, 4096)
+    for other in (oracle.random(1, 1001, 3, 4096), oracle.random(1, 1000, 4, 4096), oracle.random(2, 1000, 3, 4096), oracle.random(1 << 32, 1000, 3, 4096)):
+        assert not np.array_equal(base, other)
+        assert abs(np.corrcoef(base, other)[0, 1]) < 0.06
+
+
+def test_first_draws_across_pixels_are_uniform():
+    firsts = np.array([oracle.random(9, p, 1, 1)[0] for p in range(20000)])
+    assert abs(firsts.mean() - 0.5) < 0.01
+    counts, _ = np.histogram(firsts, bins=16, range=(0, 1))
+    assert ((counts - 1250) ** 2 / 1250).sum() < 50
+
+
+# ---- whole-frame behaviour -----------------------------------------------------------------------------------------------
+def test_sample_zero_goes_through_the_pixel_centre_and_is_seed_independent():
+    # spp = 1, max_bounces = 1: no random draw is consumed at all (mg_ray_tracer.cpp:189)
+    scene = rt_amd.Scene.named("basic").set_sampling(1, 1)
+    pod = scene.describe(64, 36)
+    a, _, _ = oracle.render(pod, 64, 36, seed=1)
+    b, _, _ = oracle.render(pod, 64, 36, seed=999)
+    assert np.array_equal(a, b)
+
+
+def test_empty_scene_is_pure_sky():
+    pod = rt_amd.scene_from_arrays(samples_per_pixel=3, max_bounces=4, inverse_view_projection=rt_amd.Scene.named("basic").describe(32, 16).inverse_view_projection[:])
+    rgba, rgb, stats = oracle.render(pod, 32, 16, seed=5)
+    assert stats["segments"] == 32 * 16 * 3
+    assert np.all(unpack(rgba)[..., 2] == 255)  # sky blue channel is exactly 1
+    assert np.all(rgb[..., 2] == 1.0)
+
+
+def test_iterative_and_recursive_trace_agree_to_rounding():
+    scene = rt_amd.Scene.named("dielectric").set_sampling(16)
+    pod = scene.describe(96, 54)
+    it_rgba, it_rgb, it_stats = oracle.render(pod, 96, 54, seed=11, trace_order=oracle.TRACE_ITERATIVE)
+    re_rgba, re_rgb, re_stats = oracle.render(pod, 96, 54, seed=11, trace_order=oracle.TRACE_RECURSIVE)
+    assert it_stats["segments"] == re_stats["segments"]  # same paths, only the product association differs
+    assert np.allclose(it_rgb, re_rgb, rtol=2e-6, atol=1e-7)
+    diff = np.abs(unpack(it_rgba).astype(int) - unpack(re_rgba).astype(int))
+    assert diff.max() <= 1 and (diff > 0).mean() < 0.002
+
+
+def test_partition_invariance_of_the_oracle():
+    scene = rt_amd.Scene.named("basic").set_sampling(3)
+    width, height = 50, 37
+    pod = scene.describe(width, height)
+    full, full_rgb, full_stats = oracle.render(pod, width, height, seed=21)
+    from rt_amd import distributed
+
+    for world, stripe in [(2, 8), (3, 4), (8, 8), (5, 1)]:
+        table = distributed.local_row_table(height, world, stripe)
+        segments = 0
+        for rank in range(world):
+            part, part_rgb, st = oracle.render(pod, width, height, seed=21, partition=(rank, world, stripe))
+            segments += st["segments"]
+            rows = np.nonzero(table[:, 0] == rank)[0]
+            assert np.array_equal(part, full[rows])
+            assert np.array_equal(part_rgb, full_rgb[rows])
+        assert segments == full_stats["segments"]
+
+
+def test_counter_streams_and_mt19937_agree_statistically():
+    """The reproducible counter streams must not change the statistics of the image: compare with the
+    reference-faithful thread_local std::mt19937 model (src/random.cpp:9-26) at the same spp."""
+    scene = rt_amd.Scene.named("basic").set_sampling(64)
+    width, height = 96, 54
+    pod = scene.describe(width, height)
+    _, counter_rgb, counter_stats = oracle.render(pod, width, height, seed=4)
+    _, mt_rgb, mt_stats = oracle.render_mt19937(pod, width, height, fixed_seed=1234, want_rgb=True)
+    assert np.allclose(counter_rgb.mean(axis=(0, 1)), mt_rgb.mean(axis=(0, 1)), rtol=0.01)
+    assert counter_stats["segments"] == pytest.approx(mt_stats["segments"], rel=0.01)
+    # per-pixel: 8x8 block means agree within Monte-Carlo noise
+    blocks = lambda img: img[: height // 6 * 6, : width // 8 * 8].reshape(height // 6, 6, width // 8, 8, 3).mean(axis=(1, 3))
+    assert np.abs(blocks(counter_rgb) - blocks(mt_rgb)).max() < 0.06
+
+
+def test_monte_carlo_error_falls_as_one_over_sqrt_spp():
+    width, height = 48, 27
+    errs = []
+    ref_scene = rt_amd.Scene.named("basic").set_sampling(8000)
+    _, ref, _ = oracle.render(ref_scene.describe(width, height), width, height, seed=100)
+    for spp in (4, 16, 64):
+        scene = rt_amd.Scene.named("basic").set_sampling(spp)
+        _, rgb, _ = oracle.render(scene.describe(width, height), width, height, seed=200 + spp)
+        errs.append(np.sqrt(((rgb - ref) ** 2).mean()))
+    # sample 0 of every pixel is the un-jittered centre ray (mg_ray_tracer.cpp:189), so low-spp images carry a small
+    # aliasing bias at silhouettes on top of the 1/sqrt(spp) noise: allow for it
+    assert 1.4 < errs[0] / errs[1] < 2.6 and 1.4 < errs[1] / errs[2] < 2.6, errs
