@@ -133,16 +133,19 @@ typedef struct rt_hip_stats
 enum
 {
 	RT_HIP_KERNEL_NONE		= 0,
-	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup */
-	RT_HIP_KERNEL_TILED		= 2	 /* primitives streamed through LDS in tiles (large scenes) */
+	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup (<= 1024 primitives) */
+	RT_HIP_KERNEL_TILED		= 2, /* primitives streamed from the SoA columns through LDS in tiles (large scenes) */
+	RT_HIP_KERNEL_SMALL		= 3	 /* <= 8 spheres, no planes: scene in scalar registers, scan fully unrolled */
 };
 
 /* Render flags.  0 = the parity contract: arithmetic bit-identical to oracle/ (see DESIGN.md §3). */
 enum
 {
 	RT_HIP_FLAG_NONE = 0u,
-	/* force the LDS-tiled kernel even for scenes that fit the resident kernel (testing) */
-	RT_HIP_FLAG_FORCE_TILED = 1u << 0
+	/* force the LDS-tiled kernel even for scenes that fit a smaller one (testing) */
+	RT_HIP_FLAG_FORCE_TILED = 1u << 0,
+	/* force the LDS-resident kernel for scenes that would take the scalar-register one (testing) */
+	RT_HIP_FLAG_FORCE_RESIDENT = 1u << 1
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;
@@ -249,6 +252,12 @@ rt_hip_status rt_hip_kat_closest_hit(rt_hip_ctx* ctx,
 
 /* out_sqrt[i] = sqrtf(a[i]), out_div[i] = a[i] / b[i] as the device computes them (must be correctly rounded). */
 rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
+
+/* Runs ALL 2^32 binary32 bit patterns through the kernels' shortened sqrt / reciprocal / reciprocal-sqrt sequences and
+ * compares each result, bit for bit, with the compiler's general correctly rounded expansion.
+ * out_mismatches[k] = number of differing inputs, out_first[k] = smallest differing input's bits (valid if count > 0),
+ * k = 0 sqrt, 1 reciprocal, 2 reciprocal of sqrt.  All three counts must be 0. */
+rt_hip_status rt_hip_kat_exhaustive_math(rt_hip_ctx* ctx, uint64_t out_mismatches[3], uint32_t out_first[3]);
 
 #ifdef __cplusplus
 }

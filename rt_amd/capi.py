@@ -19,7 +19,8 @@ LIB_DIR = Path(__file__).resolve().parent / "lib"
 RT_HIP_ABI_VERSION = 1
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
-KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled"}
+RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
+KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small"}
 
 STATUS_NAMES = {
     0: "RT_HIP_OK",
@@ -114,6 +115,7 @@ RT_HIP_SYMBOLS = [
     ("rt_hip_kat_random", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("rt_hip_kat_closest_hit", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_hip_kat_sqrt_div", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    ("rt_hip_kat_exhaustive_math", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64 * 3), C.POINTER(C.c_uint32 * 3)]),
 ]
 
 RT_HOST_SYMBOLS = [

@@ -112,6 +112,7 @@ struct rt_hip_ctx
 	// the scene, resident in HBM: one buffer holding every column back to back (256-byte aligned starts)
 	device_buffer scene_columns;
 	device_scene scene{};
+	small_scene small{}; // host copy of the kernel-argument scene of the `small` kernel
 	bool have_scene = false;
 	uint32_t samples_per_pixel = 0, max_bounces = 0;
 	float inverse_view_projection[16]{};
@@ -288,6 +289,10 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	const size_t o_pnx = place(plane_bytes), o_pny = place(plane_bytes), o_pnz = place(plane_bytes), o_pd = place(plane_bytes), o_pm = place(plane_bytes);
 	const size_t o_shading = place(static_cast<size_t>(s.n_materials) * sizeof(float4));
 	const size_t o_type = place(static_cast<size_t>(s.n_materials) * 4);
+	const size_t n_primitives = static_cast<size_t>(s.n_spheres) + s.n_planes;
+	const size_t o_geometry = place(n_primitives * sizeof(float4));
+	const size_t o_prim_shading = place(n_primitives * sizeof(float4));
+	const size_t o_prim_metal = place(n_primitives * 4);
 	const size_t total = offset ? offset : column_alignment;
 
 	// host image of the block (one H2D copy)
@@ -318,6 +323,38 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 		put(o_shading + m * sizeof(float4), shading, sizeof(shading));
 	}
 	put(o_type, s.material_type, static_cast<size_t>(s.n_materials) * 4);
+	// derived per-primitive tables (spheres, then planes)
+	ctx->small = small_scene{};
+	for (size_t i = 0; i < n_primitives; i++)
+	{
+		const bool is_sphere = i < s.n_spheres;
+		const size_t k = is_sphere ? i : i - s.n_spheres;
+		float geometry[4];
+		uint32_t material;
+		if (is_sphere)
+		{
+			const float r = s.sphere_radius[k];
+			geometry[0] = s.sphere_center_x[k], geometry[1] = s.sphere_center_y[k], geometry[2] = s.sphere_center_z[k];
+			geometry[3] = r * r; // radius^2, as hits_sphere squares it
+			material = s.sphere_material[k];
+		}
+		else
+		{
+			geometry[0] = s.plane_normal_x[k], geometry[1] = s.plane_normal_y[k], geometry[2] = s.plane_normal_z[k];
+			geometry[3] = s.plane_d[k];
+			material = s.plane_material[k];
+		}
+		const uint32_t metal = s.material_type[material] == RT_HIP_MATERIAL_METAL ? 1u : 0u;
+		put(o_geometry + i * sizeof(float4), geometry, sizeof(geometry));
+		std::memcpy(host.data() + o_prim_shading + i * sizeof(float4), host.data() + o_shading + material * sizeof(float4), sizeof(float4));
+		put(o_prim_metal + i * 4, &metal, 4);
+		if (is_sphere && i < scalar_max_spheres)
+		{
+			std::memcpy(&ctx->small.geometry[i], geometry, sizeof(geometry));
+			std::memcpy(&ctx->small.shading[i], host.data() + o_shading + material * sizeof(float4), sizeof(float4));
+			ctx->small.metal[i] = metal;
+		}
+	}
 
 	RT_HIP_TRY(hipDeviceSynchronize()); // a previous frame may still be reading the old scene
 	RT_HIP_TRY(ctx->scene_columns.reserve(total));
@@ -340,6 +377,9 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	d.plane_material = reinterpret_cast<const uint32_t*>(base + o_pm);
 	d.material_shading = reinterpret_cast<const float4*>(base + o_shading);
 	d.material_type = reinterpret_cast<const uint32_t*>(base + o_type);
+	d.primitive_geometry = reinterpret_cast<const float4*>(base + o_geometry);
+	d.primitive_shading = reinterpret_cast<const float4*>(base + o_prim_shading);
+	d.primitive_metal = reinterpret_cast<const uint32_t*>(base + o_prim_metal);
 
 	ctx->samples_per_pixel = s.samples_per_pixel;
 	ctx->max_bounces = s.max_bounces;
@@ -365,7 +405,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
 	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
-	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED))
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
 	if (!ctx->have_scene)
 		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
@@ -397,10 +437,15 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		f.k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
 		f.k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
 	}
+	// w = fma(mx[3], ndc.x, fma(my[3], ndc.y, k[3])) is exactly k[3] for every finite ndc when mx[3] and my[3] are
+	// (+-)0 and k[3] is not: then the per-sample 1/w is this one constant
+	f.uniform_w = (f.mx[3] == 0.0f && f.my[3] == 0.0f && f.k_near[3] != 0.0f && f.k_far[3] != 0.0f && std::isfinite(f.k_near[3]) && std::isfinite(f.k_far[3])) ? 1u : 0u;
+	f.inv_w_near = f.uniform_w ? 1.0f / f.k_near[3] : 0.0f;
+	f.inv_w_far = f.uniform_w ? 1.0f / f.k_far[3] : 0.0f;
 
 	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
 	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
-	const uint32_t variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_FORCE_TILED) != 0, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	const uint32_t variant = launch_render(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
 	ctx->render_recorded = true;
@@ -554,5 +599,24 @@ extern "C" rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const 
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipMemcpy(out_sqrt, out, bytes, hipMemcpyDeviceToHost));
 	RT_HIP_TRY(hipMemcpy(out_div, out + bytes, bytes, hipMemcpyDeviceToHost));
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_kat_exhaustive_math(rt_hip_ctx* ctx, uint64_t out_mismatches[3], uint32_t out_first[3])
+{
+	if (!ctx || !out_mismatches || !out_first)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_kat_exhaustive_math: NULL argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	RT_HIP_TRY(ctx->kat_out.reserve(6 * sizeof(unsigned long long)));
+	unsigned long long host[6] = { 0, ~0ull, 0, ~0ull, 0, ~0ull };
+	RT_HIP_TRY(hipMemcpy(ctx->kat_out.ptr, host, sizeof(host), hipMemcpyHostToDevice));
+	launch_kat_exhaustive_math(ctx->kat_out.as<unsigned long long>(), nullptr);
+	RT_HIP_TRY(hipGetLastError());
+	RT_HIP_TRY(hipMemcpy(host, ctx->kat_out.ptr, sizeof(host), hipMemcpyDeviceToHost));
+	for (int f = 0; f < 3; f++)
+	{
+		out_mismatches[f] = host[2 * f];
+		out_first[f] = host[2 * f] ? static_cast<uint32_t>(host[2 * f + 1] - 1ull) : 0u;
+	}
 	return ok();
 }

@@ -30,10 +30,98 @@ namespace rt_hip
 	// dot(a,b) = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
 	__device__ __forceinline__ float dot(vec3 a, vec3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
 
+	// ---- correctly rounded sqrt and reciprocal, cheaper than hipcc's general expansions ------------------------
+	// hipcc expands __builtin_sqrtf and '/' into sequences that are correct for every input (subnormals,
+	// infinities, overflow of intermediates): ~22 and ~18 full-rate VALU slots each (profiles/r01/microbench_valu.txt).
+	// Inside a band of exponents where no intermediate can overflow or underflow the core of those sequences is
+	// enough.  The functions below take the core when the argument lies in the band and fall back to the general
+	// expansion otherwise (a wave-uniform branch that is practically never taken), so their results are
+	// BIT-IDENTICAL to __builtin_sqrtf(x), 1.0f / x and 1.0f / __builtin_sqrtf(x) for EVERY input; this is checked
+	// on the device over all 2^32 bit patterns by rt_hip_kat_exhaustive_math (tests/test_gpu_parity.py).
+	__device__ __forceinline__ bool in_fast_band(float x) // 2^-60 <= x < 2^60 (positive, finite, normal)
+	{
+		return (__float_as_uint(x) - 0x21800000u) < (0x5D800000u - 0x21800000u);
+	}
+
+	__device__ __forceinline__ float sqrt_core(float x, float& half_rsq)
+	{
+		// Goldschmidt iteration seeded by v_rsq_f32 (1 ulp), residual-corrected: correctly rounded in the band
+		const float r = __builtin_amdgcn_rsqf(x);
+		float s = x * r;
+		float h = 0.5f * r;
+		const float e = fma(-h, s, 0.5f);
+		h = fma(h, e, h);
+		s = fma(s, e, s);
+		const float d = fma(-s, s, x);
+		s = fma(d, h, s);
+		half_rsq = h;
+		return s;
+	}
+
+	__device__ __forceinline__ float rcp_core(float x, float seed)
+	{
+		// the refinement steps of the IEEE division expansion for 1/x, without the range scaling
+		float r = seed;
+		const float e0 = fma(-x, r, 1.0f);
+		r = fma(e0, r, r);
+		float q = r;
+		const float e1 = fma(-x, q, 1.0f);
+		q = fma(e1, r, q);
+		const float e2 = fma(-x, q, 1.0f);
+		q = fma(e2, r, q);
+		return q;
+	}
+
+	// == __builtin_sqrtf(x)
+	__device__ __forceinline__ float sqrt_rn(float x)
+	{
+		const bool fast = in_fast_band(x);
+		float h;
+		float s = sqrt_core(fast ? x : 1.0f, h);
+		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		{
+			const float general = __builtin_sqrtf(x);
+			s = fast ? s : general;
+		}
+		return s;
+	}
+
+	// == 1.0f / x
+	__device__ __forceinline__ float rcp_rn(float x)
+	{
+		const bool fast = in_fast_band(__builtin_fabsf(x));
+		const float xs = fast ? x : 1.0f;
+		float q = rcp_core(xs, __builtin_amdgcn_rcpf(xs));
+		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		{
+			const float general = 1.0f / x;
+			q = fast ? q : general;
+		}
+		return q;
+	}
+
+	// == 1.0f / __builtin_sqrtf(x): both roundings kept.  (Seeding the reciprocal with the square root's own
+	// v_rsq_f32 estimate instead of v_rcp_f32 saves a transcendental but is NOT exact: it misses the correctly
+	// rounded quotient for the 120 inputs just below an even power of two — exactly what normalising an already
+	// unit-length direction produces — as rt_hip_kat_exhaustive_math showed.)
+	__device__ __forceinline__ float inv_sqrt_rn(float x)
+	{
+		const bool fast = in_fast_band(x);
+		float h;
+		const float s = sqrt_core(fast ? x : 1.0f, h); // in [2^-30, 2^30): inside the reciprocal's band as well
+		float q = rcp_core(s, __builtin_amdgcn_rcpf(s));
+		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		{
+			const float general = 1.0f / __builtin_sqrtf(x);
+			q = fast ? q : general;
+		}
+		return q;
+	}
+
 	// normalize(v) = v * (1 / sqrt(dot(v,v)))
 	__device__ __forceinline__ vec3 normalize(vec3 v)
 	{
-		const float inv = 1.0f / __builtin_sqrtf(dot(v, v));
+		const float inv = inv_sqrt_rn(dot(v, v));
 		return v * inv;
 	}
 
@@ -93,7 +181,7 @@ namespace rt_hip
 		const float disc = r2 - fma(-a, a, e2);
 		if (disc < 0.0f)
 			return false;
-		const float f = __builtin_sqrtf(disc);
+		const float f = sqrt_rn(disc);
 		t = (e2 < r2) ? a + f : a - f;
 		if (t < 0.0f)
 			return false;

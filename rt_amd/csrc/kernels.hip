@@ -12,12 +12,18 @@
 //     lane whose path ended adds its sample and starts the next one in the same trip.  A wave therefore runs for
 //     max-over-lanes of the TOTAL segment count of a pixel (which concentrates around spp x mean path length),
 //     not for sum-over-samples of the max-over-lanes path length;
-//   * `resident` kernel: all primitives are staged ONCE per workgroup from the SoA columns into LDS as
-//     (cx, cy, cz, r^2) / (nx, ny, nz, d) float4s; the scan reads them with wave-uniform addresses, i.e. one
-//     broadcast ds_read_b128 per primitive per wave and no bank conflicts;
-//   * `tiled` kernel (scenes that do not fit): the same scan, but primitives stream through LDS in tiles of
-//     tile_primitives; the workgroup moves in lock step (one segment per trip, barriers around each tile).
-// No MFMA: this is intersection arithmetic (subtract/dot/compare/sqrt), not a contraction.
+//   * the closest-hit scan reads every primitive with a WAVE-UNIFORM address and skips a primitive's square
+//     root when no lane of the wave can hit it (one ballot);
+//   * three kernels, chosen by scene size:
+//       small    (<= 8 spheres, no planes: basic.toml, dielectric.toml): the spheres arrive as kernel arguments and
+//                live in SGPRs; the scan is fully unrolled straight-line code with scalar operands; only the
+//                per-lane lookups of the winning sphere go through LDS;
+//       resident (<= 1024 primitives): all primitives are staged ONCE per workgroup into LDS as float4s; the scan
+//                reads them as broadcast ds_read_b128 (no bank conflicts), software-prefetched one primitive ahead;
+//       tiled    (anything larger): primitives stream from the SoA columns in HBM through LDS in tiles of 1024
+//                (coalesced dword loads per column, radius squared on the way in); the workgroup moves in lock
+//                step, one path segment per trip, with barriers around each tile.
+// No MFMA: this is intersection arithmetic (subtract / dot / compare / sqrt), not a contraction.
 #include "kernels.hpp"
 #include "contract.hpp"
 
@@ -31,53 +37,67 @@ namespace rt_hip
 		constexpr uint32_t block_pixels_x = 32;
 		constexpr uint32_t block_pixels_y = 8;
 
-		// hit_result, mg_ray_tracer.cpp:22-33 (distance < 0 = miss)
-		struct hit_result
-		{
-			float distance;
-			vec3 normal;
-			uint32_t material;
-			uint32_t kind; // 0 none, 1 sphere, 2 plane
-			uint32_t index;
-		};
-
 		// best candidate of one linear scan (test_planes / test_spheres, mg_ray_tracer.cpp:36-87)
-		struct scan_result
+		struct candidate
 		{
-			bool have;
-			float distance;
+			float t;
 			uint32_t index;
+			bool have;
 		};
 
-		// one step of the scan loop: `if (!hit || *hit < min_hit_dist || (hit_index && hit_dist <= *hit)) continue;`
-		__device__ __forceinline__ void scan_accept(scan_result& best, bool hit, float t, uint32_t index)
+		// One sphere of test_spheres (:70-79) for all lanes at once.  `s` = (center, radius^2), wave-uniform.
+		__device__ __forceinline__ void test_sphere(candidate& best, vec3 o, vec3 d, float4 s, uint32_t index)
 		{
-			if (!hit || t < min_hit_dist || (best.have && best.distance <= t))
-				return;
-			best.have = true;
-			best.index = index;
-			best.distance = t;
-		}
-
-		__device__ __forceinline__ void scan_spheres(scan_result& best, vec3 o, vec3 d, const float4* lds_spheres, uint32_t count, uint32_t first_index)
-		{
-			for (uint32_t i = 0; i < count; i++)
+			const vec3 e = { s.x - o.x, s.y - o.y, s.z - o.z };
+			const float a = dot(e, d);
+			const float e2 = dot(e, e);
+			const float disc = s.w - fma(-a, a, e2);
+			const bool pos = !(disc < 0.0f); // hits_sphere: `if (disc < 0) return nullopt`
+			if (__builtin_amdgcn_ballot_w64(pos) != 0) // no lane can hit: skip the square root for the whole wave
 			{
-				const float4 s = lds_spheres[i]; // wave-uniform address: broadcast read
-				float t = 0.0f;
-				const bool hit = hits_sphere(o, d, { s.x, s.y, s.z }, s.w, t);
-				scan_accept(best, hit, t, first_index + i);
+				const float f = sqrt_rn(pos ? disc : 1.0f);
+				const float t = (e2 < s.w) ? a + f : a - f;
+				// hits() holds a value <=> pos && !(t < 0); the scan then drops t < min_hit_dist (which covers
+				// t < 0) and anything not closer than the best so far: `hit_index && hit_dist <= *hit` (:74)
+				const bool accept = pos && !(t < min_hit_dist) && !(best.have && best.t <= t);
+				best.t = accept ? t : best.t;
+				best.index = accept ? index : best.index;
+				best.have = best.have || accept;
 			}
 		}
 
-		__device__ __forceinline__ void scan_planes(scan_result& best, vec3 o, vec3 d, const float4* lds_planes, uint32_t count, uint32_t first_index)
+		// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
+		__device__ __forceinline__ void test_plane(candidate& best, vec3 o, vec3 d, float4 pl, uint32_t index)
 		{
+			const vec3 n = { pl.x, pl.y, pl.z };
+			const float den = dot(n, d);
+			const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
+			if (__builtin_amdgcn_ballot_w64(crosses) != 0)
+			{
+				const float num = dot(n, o) + pl.w;
+				const float t = (-num) / (crosses ? den : 1.0f);
+				const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
+				best.t = accept ? t : best.t;
+				best.index = accept ? index : best.index;
+				best.have = best.have || accept;
+			}
+		}
+
+		// scan `count` primitives held in LDS, reading one primitive ahead of the arithmetic
+		template <bool SPHERES>
+		__device__ __forceinline__ void scan_lds(candidate& best, vec3 o, vec3 d, const float4* lds, uint32_t count, uint32_t first_index)
+		{
+			if (!count)
+				return;
+			float4 current = lds[0]; // wave-uniform address: broadcast read
 			for (uint32_t i = 0; i < count; i++)
 			{
-				const float4 pl = lds_planes[i];
-				float t = 0.0f;
-				const bool hit = hits_plane(o, d, { pl.x, pl.y, pl.z }, pl.w, t);
-				scan_accept(best, hit, t, first_index + i);
+				const float4 next = lds[i + 1 < count ? i + 1 : i];
+				if (SPHERES)
+					test_sphere(best, o, d, current, first_index + i);
+				else
+					test_plane(best, o, d, current, first_index + i);
+				current = next;
 			}
 		}
 
@@ -98,44 +118,20 @@ namespace rt_hip
 				lds[i] = make_float4(s.plane_nx[first + i], s.plane_ny[first + i], s.plane_nz[first + i], s.plane_d[first + i]);
 		}
 
-		// select(test_spheres, test_planes) then select(test_boxes, ...) — mg_ray_tracer.cpp:96-102,160-162.
-		// `operator bool` of hit_result is `distance >= 0` (:29-32), which also rejects a NaN distance.
-		__device__ __forceinline__ hit_result resolve_hit(const device_scene& s, vec3 o, vec3 d, const scan_result& spheres, const scan_result& planes)
+		// select(test_spheres, test_planes), then select(test_boxes, ...) which never changes anything —
+		// mg_ray_tracer.cpp:96-102,160-162.  `operator bool` of hit_result is `distance >= 0` (:29-32), which also
+		// rejects a NaN distance.  Returns 0 = miss, 1 = sphere, 2 = plane.
+		__device__ __forceinline__ uint32_t select_hit(const candidate& spheres, const candidate& planes, float& distance, uint32_t& index)
 		{
-			const float sphere_distance = spheres.have ? spheres.distance : -1.0f;
-			const float plane_distance = planes.have ? planes.distance : -1.0f;
+			const float sphere_distance = spheres.have ? spheres.t : -1.0f;
+			const float plane_distance = planes.have ? planes.t : -1.0f;
 			const bool a = sphere_distance >= 0.0f;
 			const bool b = plane_distance >= 0.0f;
-			hit_result h;
-			if (a && (!b || sphere_distance <= plane_distance))
-			{
-				const uint32_t i = spheres.index;
-				const vec3 center = { s.sphere_cx[i], s.sphere_cy[i], s.sphere_cz[i] };
-				h.distance = sphere_distance;
-				h.normal = normalize(ray_at(o, d, sphere_distance) - center); // vec3::direction(center, r.at(t)), :85
-				h.material = s.sphere_material[i];
-				h.kind = 1;
-				h.index = i;
-			}
-			else if (b)
-			{
-				const uint32_t i = planes.index;
-				h.distance = plane_distance;
-				h.normal = { s.plane_nx[i], s.plane_ny[i], s.plane_nz[i] };
-				h.material = s.plane_material[i];
-				h.kind = 2;
-				h.index = i;
-			}
-			else
-			{
-				// note: when a is false and b is false the reference returns b's (negative) distance: a miss
-				h.distance = -1.0f;
-				h.normal = { 0, 0, 0 };
-				h.material = 0;
-				h.kind = 0;
-				h.index = 0;
-			}
-			return h;
+			const bool use_sphere = a && (!b || sphere_distance <= plane_distance);
+			const bool use_plane = !use_sphere && b;
+			distance = use_sphere ? sphere_distance : (use_plane ? plane_distance : -1.0f);
+			index = use_sphere ? spheres.index : planes.index;
+			return use_sphere ? 1u : (use_plane ? 2u : 0u);
 		}
 
 		// everything a lane carries between loop trips
@@ -166,15 +162,19 @@ namespace rt_hip
 			const float py = st.fy + jy;
 			const float ndc_x = fma(px, p.sx, -1.0f);
 			const float ndc_y = fma(py, p.neg_sy, 1.0f);
-			float near_row[4], far_row[4];
+			float near_row[3], far_row[3];
 #pragma unroll
-			for (int r = 0; r < 4; r++)
+			for (int r = 0; r < 3; r++)
 			{
 				near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
 				far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
 			}
-			const float inv_wn = 1.0f / near_row[3];
-			const float inv_wf = 1.0f / far_row[3];
+			float inv_wn = p.inv_w_near, inv_wf = p.inv_w_far;
+			if (!p.uniform_w) // wave-uniform (kernel argument)
+			{
+				inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
+				inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
+			}
 			const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
 			const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
 			st.origin = near_pos;
@@ -183,53 +183,44 @@ namespace rt_hip
 			st.bounces_left = p.max_bounces;
 		}
 
-		// the part of trace() after the closest-hit query (:163-173) for one segment.
-		// returns true when the path ended; `contribution` is then the sample's value.
-		__device__ __forceinline__ bool shade_segment(lane_state& st, const device_scene& s, const hit_result& hit, vec3& contribution)
+		// The part of trace() after the closest-hit query (:163-173) for one segment.
+		// kind 0 = miss; otherwise `normal` is the hit normal, `shading` = (attenuation.rgb, roughness), `metal` the
+		// scatter function (:142-152).  Returns true when the path ended; `contribution` is then the sample's value.
+		__device__ __forceinline__ bool
+		shade_segment(lane_state& st, uint32_t kind, float distance, vec3 normal, float4 shading, bool metal, vec3& contribution)
 		{
-			if (!(hit.distance >= 0.0f))
+			if (!kind)
 			{
-				contribution = st.throughput * sky(st.dir.y);
+				contribution = st.throughput * sky(st.dir.y); // :163-164
 				return true;
 			}
-			const float4 shading = s.material_shading[hit.material];
-			const bool metal = s.material_type[hit.material] == RT_HIP_MATERIAL_METAL; // everything else is lambert (:142-152)
-			const vec3 hit_pos = ray_at(st.origin, st.dir, hit.distance);
-
-			vec3 base = hit.normal;
+			const vec3 hit_pos = ray_at(st.origin, st.dir, distance);
+			vec3 base = normal;
 			float spread = 1.0f;
 			if (metal)
 			{
 				// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
 				const vec3 v = normalize(st.dir);
-				const float k = 2.0f * dot(v, hit.normal);
-				base = { fma(-k, hit.normal.x, v.x), fma(-k, hit.normal.y, v.y), fma(-k, hit.normal.z, v.z) };
+				const float k = 2.0f * dot(v, normal);
+				base = { fma(-k, normal.x, v.x), fma(-k, normal.y, v.y), fma(-k, normal.z, v.z) };
 				spread = shading.w;
 			}
 			const vec3 u = random_unit_vector(st.counter);
 			// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
 			vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
+			bool absorbed = false;
 			if (metal)
-			{
-				if (dot(scatter, hit.normal) <= 0.0f) // absorbed (:135-136)
-				{
-					contribution = { 0.0f, 0.0f, 0.0f };
-					return true;
-				}
-			}
+				absorbed = dot(scatter, normal) <= 0.0f; // (:135-136)
 			else if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon
 					 && __builtin_fabsf(scatter.z) <= approx_zero_epsilon)
-				scatter = hit.normal; // (:118-119)
+				scatter = normal; // (:118-119)
 
 			st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
 			st.origin = hit_pos;
 			st.dir = normalize(scatter);
-			if (st.bounces_left == 0) // the next trace() call would return {} at :157-158
-			{
-				contribution = { 0.0f, 0.0f, 0.0f };
-				return true;
-			}
-			return false;
+			// absorbed, or the next trace() call would return {} at :157-158
+			contribution = { 0.0f, 0.0f, 0.0f };
+			return absorbed || st.bounces_left == 0;
 		}
 
 		__device__ __forceinline__ uint32_t global_row(uint32_t local_row, const frame_params& p)
@@ -237,13 +228,15 @@ namespace rt_hip
 			return ((local_row / p.stripe_rows) * p.world + p.rank) * p.stripe_rows + (local_row % p.stripe_rows);
 		}
 
-		// pixel owned by this lane; false if outside this rank's part of the frame
+		// Pixel owned by this lane; false if outside this rank's part of the frame.  Workgroups are handed out
+		// bottom row first: the lower part of a frame is usually the expensive one (ground under sky), and starting
+		// with it keeps the cheap sky tiles for the tail of the launch.
 		__device__ __forceinline__ bool lane_pixel(const frame_params& p, uint32_t& lx, uint32_t& ly)
 		{
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
 			lx = blockIdx.x * block_pixels_x + wave * 8u + (lane & 7u);
-			ly = blockIdx.y * block_pixels_y + (lane >> 3);
+			ly = (gridDim.y - 1u - blockIdx.y) * block_pixels_y + (lane >> 3);
 			return lx < p.width && ly < p.local_rows;
 		}
 
@@ -283,18 +276,28 @@ namespace rt_hip
 				atomicAdd(&counters->segments, total);
 		}
 
-		// ---- resident kernel ------------------------------------------------------------------------------------
-		__global__ __launch_bounds__(block_threads) void render_resident(const frame_params p,
-																		 const device_scene s,
-																		 uint32_t* __restrict__ out_rgba,
-																		 float* __restrict__ out_rgb,
-																		 device_counters* __restrict__ counters)
+		// ---- small kernel: <= 8 spheres, no planes; the scene is a kernel argument ----------------------------------
+		template <int NS>
+		__global__ __launch_bounds__(block_threads) void render_small(const frame_params p,
+																	  const small_scene scene,
+																	  uint32_t* __restrict__ out_rgba,
+																	  float* __restrict__ out_rgb,
+																	  device_counters* __restrict__ counters)
 		{
-			extern __shared__ float4 lds[];
-			float4* const lds_spheres = lds;
-			float4* const lds_planes = lds + s.n_spheres;
-			stage_spheres(lds_spheres, s, 0, s.n_spheres);
-			stage_planes(lds_planes, s, 0, s.n_planes);
+			// per-lane lookups of the winning sphere (its index differs from lane to lane) go through LDS
+			__shared__ float4 lds_geometry[scalar_max_spheres];
+			__shared__ float4 lds_shading[scalar_max_spheres];
+			__shared__ uint32_t lds_metal[scalar_max_spheres];
+			if (threadIdx.x == 0)
+			{
+#pragma unroll
+				for (int i = 0; i < NS; i++) // constant indices: the argument block is never indexed dynamically
+				{
+					lds_geometry[i] = scene.geometry[i];
+					lds_shading[i] = scene.shading[i];
+					lds_metal[i] = scene.metal[i];
+				}
+			}
 			__syncthreads();
 
 			uint32_t lx, ly;
@@ -308,13 +311,94 @@ namespace rt_hip
 				{
 					st.bounces_left--;
 					st.segments++;
-					scan_result planes = { false, 0.0f, 0 };
-					scan_result spheres = { false, 0.0f, 0 };
-					scan_planes(planes, st.origin, st.dir, lds_planes, s.n_planes, 0);
-					scan_spheres(spheres, st.origin, st.dir, lds_spheres, s.n_spheres, 0);
-					const hit_result hit = resolve_hit(s, st.origin, st.dir, spheres, planes);
+					candidate best = { 0.0f, 0u, false };
+#pragma unroll
+					for (int i = 0; i < NS; i++)
+						test_sphere(best, st.origin, st.dir, scene.geometry[i], static_cast<uint32_t>(i)); // SGPR operands
+					const bool hit = best.have && best.t >= 0.0f;
+					vec3 normal = { 0.0f, 0.0f, 0.0f };
+					float4 shading = { 0.0f, 0.0f, 0.0f, 0.0f };
+					bool metal = false;
+					if (hit)
+					{
+						const float4 g = lds_geometry[best.index];
+						shading = lds_shading[best.index];
+						metal = lds_metal[best.index] != 0;
+						// vec3::direction(center, r.at(t)) (:85)
+						normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z });
+					}
 					vec3 contribution;
-					if (shade_segment(st, s, hit, contribution))
+					if (shade_segment(st, hit ? 1u : 0u, best.t, normal, shading, metal, contribution))
+					{
+						st.colour = st.colour + contribution;
+						if (++st.sample >= p.samples_per_pixel)
+							break;
+						start_sample(st, p);
+					}
+				}
+				finish_pixel(st, p, lx, ly, out_rgba, out_rgb);
+			}
+			add_segments(counters, st.segments);
+		}
+
+		// lookups of the winning primitive for the LDS kernels (global tables; one indexed read each)
+		__device__ __forceinline__ void
+		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, bool& metal)
+		{
+			normal = { 0.0f, 0.0f, 0.0f };
+			shading = { 0.0f, 0.0f, 0.0f, 0.0f };
+			metal = false;
+			if (kind)
+			{
+				const uint32_t primitive = kind == 1u ? index : s.n_spheres + index;
+				const float4 g = s.primitive_geometry[primitive];
+				shading = s.primitive_shading[primitive];
+				metal = s.primitive_metal[primitive] != 0;
+				if (kind == 1u)
+					normal = normalize(ray_at(o, d, distance) - vec3{ g.x, g.y, g.z }); // (:85)
+				else
+					normal = { g.x, g.y, g.z }; // the plane's normal, not flipped toward the ray (:58)
+			}
+		}
+
+		// ---- resident kernel ------------------------------------------------------------------------------------
+		__global__ __launch_bounds__(block_threads) void render_resident(const frame_params p,
+																		 const device_scene s,
+																		 uint32_t* __restrict__ out_rgba,
+																		 float* __restrict__ out_rgb,
+																		 device_counters* __restrict__ counters)
+		{
+			extern __shared__ float4 lds[];
+			float4* const lds_spheres = lds;
+			float4* const lds_planes = lds + s.n_spheres;
+			for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
+				lds[i] = s.primitive_geometry[i];
+			__syncthreads();
+
+			uint32_t lx, ly;
+			lane_state st;
+			st.segments = 0;
+			if (lane_pixel(p, lx, ly))
+			{
+				init_lane(st, p, lx, ly);
+				start_sample(st, p);
+				while (true)
+				{
+					st.bounces_left--;
+					st.segments++;
+					candidate planes = { 0.0f, 0u, false };
+					candidate spheres = { 0.0f, 0u, false };
+					scan_lds<false>(planes, st.origin, st.dir, lds_planes, s.n_planes, 0);
+					scan_lds<true>(spheres, st.origin, st.dir, lds_spheres, s.n_spheres, 0);
+					float distance;
+					uint32_t index;
+					const uint32_t kind = select_hit(spheres, planes, distance, index);
+					vec3 normal;
+					float4 shading;
+					bool metal;
+					fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+					vec3 contribution;
+					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
 					{
 						st.colour = st.colour + contribution;
 						if (++st.sample >= p.samples_per_pixel)
@@ -353,8 +437,8 @@ namespace rt_hip
 					st.bounces_left--;
 					st.segments++;
 				}
-				scan_result planes = { false, 0.0f, 0 };
-				scan_result spheres = { false, 0.0f, 0 };
+				candidate planes = { 0.0f, 0u, false };
+				candidate spheres = { 0.0f, 0u, false };
 				for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
 				{
 					const uint32_t count = min(tile_primitives, s.n_planes - first);
@@ -362,7 +446,7 @@ namespace rt_hip
 					stage_planes(tile, s, first, count);
 					__syncthreads();
 					if (alive)
-						scan_planes(planes, st.origin, st.dir, tile, count, first);
+						scan_lds<false>(planes, st.origin, st.dir, tile, count, first);
 				}
 				for (uint32_t first = 0; first < s.n_spheres; first += tile_primitives)
 				{
@@ -371,13 +455,19 @@ namespace rt_hip
 					stage_spheres(tile, s, first, count);
 					__syncthreads();
 					if (alive)
-						scan_spheres(spheres, st.origin, st.dir, tile, count, first);
+						scan_lds<true>(spheres, st.origin, st.dir, tile, count, first);
 				}
 				if (alive)
 				{
-					const hit_result hit = resolve_hit(s, st.origin, st.dir, spheres, planes);
+					float distance;
+					uint32_t index;
+					const uint32_t kind = select_hit(spheres, planes, distance, index);
+					vec3 normal;
+					float4 shading;
+					bool metal;
+					fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
 					vec3 contribution;
-					if (shade_segment(st, s, hit, contribution))
+					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
 					{
 						st.colour = st.colour + contribution;
 						if (++st.sample >= p.samples_per_pixel)
@@ -440,8 +530,8 @@ namespace rt_hip
 				o = { origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2] };
 				d = { directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2] };
 			}
-			scan_result planes = { false, 0.0f, 0 };
-			scan_result spheres = { false, 0.0f, 0 };
+			candidate planes = { 0.0f, 0u, false };
+			candidate spheres = { 0.0f, 0u, false };
 			for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
 			{
 				const uint32_t count = min(tile_primitives, s.n_planes - first);
@@ -449,7 +539,7 @@ namespace rt_hip
 				stage_planes(tile, s, first, count);
 				__syncthreads();
 				if (alive)
-					scan_planes(planes, o, d, tile, count, first);
+					scan_lds<false>(planes, o, d, tile, count, first);
 			}
 			for (uint32_t first = 0; first < s.n_spheres; first += tile_primitives)
 			{
@@ -458,17 +548,23 @@ namespace rt_hip
 				stage_spheres(tile, s, first, count);
 				__syncthreads();
 				if (alive)
-					scan_spheres(spheres, o, d, tile, count, first);
+					scan_lds<true>(spheres, o, d, tile, count, first);
 			}
 			if (alive)
 			{
-				const hit_result h = resolve_hit(s, o, d, spheres, planes);
-				out_distance[i] = h.distance;
-				out_kind[i] = h.kind;
-				out_index[i] = h.index;
-				out_normal[i * 3 + 0] = h.normal.x;
-				out_normal[i * 3 + 1] = h.normal.y;
-				out_normal[i * 3 + 2] = h.normal.z;
+				float distance;
+				uint32_t index;
+				const uint32_t kind = select_hit(spheres, planes, distance, index);
+				vec3 normal;
+				float4 shading;
+				bool metal;
+				fetch_hit(s, o, d, kind, distance, index, normal, shading, metal);
+				out_distance[i] = distance;
+				out_kind[i] = kind;
+				out_index[i] = kind ? index : 0u;
+				out_normal[i * 3 + 0] = normal.x;
+				out_normal[i * 3 + 1] = normal.y;
+				out_normal[i * 3 + 2] = normal.z;
 			}
 		}
 
@@ -481,11 +577,67 @@ namespace rt_hip
 				out_div[i] = a[i] / b[i];
 			}
 		}
+
+		// every one of the 2^32 binary32 bit patterns through sqrt_rn / rcp_rn / inv_sqrt_rn against hipcc's general
+		// correctly rounded expansions; result[2k] = mismatches, result[2k+1] = smallest mismatching input + 1
+		__device__ __forceinline__ bool same_float(float a, float b)
+		{
+			return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
+		}
+
+		__global__ __launch_bounds__(block_threads) void kat_exhaustive_math(unsigned long long* __restrict__ result)
+		{
+			const uint32_t tid = blockIdx.x * block_threads + threadIdx.x; // 2^22 threads x 2^10 patterns each
+			uint32_t bad[3] = { 0, 0, 0 };
+			unsigned long long first[3] = { ~0ull, ~0ull, ~0ull };
+			for (uint32_t k = 0; k < 1024u; k++)
+			{
+				const uint32_t bits = (k << 22) | tid;
+				const float x = __uint_as_float(bits);
+				const bool ok[3] = { same_float(sqrt_rn(x), __builtin_sqrtf(x)),
+									 same_float(rcp_rn(x), 1.0f / x),
+									 same_float(inv_sqrt_rn(x), 1.0f / __builtin_sqrtf(x)) };
+#pragma unroll
+				for (int f = 0; f < 3; f++)
+					if (!ok[f])
+					{
+						bad[f]++;
+						if (static_cast<unsigned long long>(bits) + 1ull < first[f])
+							first[f] = static_cast<unsigned long long>(bits) + 1ull;
+					}
+			}
+#pragma unroll
+			for (int f = 0; f < 3; f++)
+				if (bad[f])
+				{
+					atomicAdd(&result[2 * f], static_cast<unsigned long long>(bad[f]));
+					atomicMin(&result[2 * f + 1], first[f]);
+				}
+		}
+
+		template <int NS>
+		void launch_small(const frame_params& frame, const small_scene& scene, dim3 grid, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream)
+		{
+			hipLaunchKernelGGL(render_small<NS>, grid, dim3(block_threads), 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
+		}
+	}
+
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags)
+	{
+		const uint32_t primitives = scene.n_spheres + scene.n_planes;
+		if (flags & RT_HIP_FLAG_FORCE_TILED)
+			return RT_HIP_KERNEL_TILED;
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
+			return RT_HIP_KERNEL_SMALL;
+		if (primitives <= resident_max_primitives)
+			return RT_HIP_KERNEL_RESIDENT;
+		return RT_HIP_KERNEL_TILED;
 	}
 
 	uint32_t launch_render(const frame_params& frame,
 						   const device_scene& scene,
-						   bool force_tiled,
+						   const small_scene& small,
+						   uint32_t flags,
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
@@ -495,15 +647,32 @@ namespace rt_hip
 		const dim3 block(block_threads);
 		if (!grid.x || !grid.y)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t primitives = scene.n_spheres + scene.n_planes;
-		if (!force_tiled && primitives <= resident_max_primitives)
+		const uint32_t variant = choose_kernel(scene, flags);
+		if (variant == RT_HIP_KERNEL_SMALL)
 		{
+			const small_scene& args = small;
+			switch (scene.n_spheres)
+			{
+				case 1: launch_small<1>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 2: launch_small<2>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 3: launch_small<3>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 4: launch_small<4>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 5: launch_small<5>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 6: launch_small<6>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 7: launch_small<7>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				default: launch_small<8>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+			}
+			return variant;
+		}
+		if (variant == RT_HIP_KERNEL_RESIDENT)
+		{
+			const uint32_t primitives = scene.n_spheres + scene.n_planes;
 			const size_t lds_bytes = static_cast<size_t>(primitives ? primitives : 1u) * sizeof(float4);
 			hipLaunchKernelGGL(render_resident, grid, block, lds_bytes, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
-			return RT_HIP_KERNEL_RESIDENT;
+			return variant;
 		}
 		hipLaunchKernelGGL(render_tiled, grid, block, 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
-		return RT_HIP_KERNEL_TILED;
+		return variant;
 	}
 
 	void launch_assemble(uint32_t width,
@@ -542,5 +711,10 @@ namespace rt_hip
 	{
 		const dim3 grid((n + block_threads - 1) / block_threads);
 		hipLaunchKernelGGL(kat_sqrt_div, grid, dim3(block_threads), 0, stream, n, d_a, d_b, d_sqrt, d_div);
+	}
+
+	void launch_kat_exhaustive_math(unsigned long long* d_result, hipStream_t stream)
+	{
+		hipLaunchKernelGGL(kat_exhaustive_math, dim3((1u << 22) / block_threads), dim3(block_threads), 0, stream, d_result);
 	}
 }

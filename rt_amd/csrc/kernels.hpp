@@ -6,8 +6,13 @@
 
 namespace rt_hip
 {
-	// Scene columns resident in HBM, exactly the soagen columns the reference fills at load
-	// (src/scene.cpp:583,595) plus the per-material shading table.
+	// The scene resident in HBM.
+	//   * the soagen columns exactly as the reference fills them at load (src/scene.cpp:583,595): the LDS-tiled
+	//     kernel streams these, one coalesced dword per lane per column;
+	//   * per-primitive tables derived from them at upload: (center, radius^2) / (normal, d) as float4, and the
+	//     shading inputs of the primitive's material — (albedo.rgb * reflectivity, roughness) and a metal flag
+	//     (mg_ray_tracer.cpp:115,131,142-152) — so that a hit needs one indexed lookup instead of two dependent ones;
+	//   * the per-material shading table for kernels that only know the winning primitive's material index.
 	struct device_scene
 	{
 		uint32_t n_spheres, n_planes, n_materials;
@@ -21,24 +26,41 @@ namespace rt_hip
 		const float* plane_nz;
 		const float* plane_d;
 		const uint32_t* plane_material;
-		// per material: (albedo.rgb * reflectivity, roughness) — mg_ray_tracer.cpp:115,131 — and the type
-		const float4* material_shading;
+		const float4* material_shading; // per material: (attenuation.rgb, roughness)
 		const uint32_t* material_type;
+		// derived per-primitive tables; spheres first, then planes (index n_spheres + i)
+		const float4* primitive_geometry; // sphere: (cx, cy, cz, r*r); plane: (nx, ny, nz, d)
+		const float4* primitive_shading;  // (attenuation.rgb, roughness) of the primitive's material
+		const uint32_t* primitive_metal;  // 1 if the primitive's material is metal, else 0
 	};
 
 	// Per-frame uniforms (kernel arguments -> SGPRs).
 	struct frame_params
 	{
-		uint32_t width, height;			  // full frame
-		uint32_t local_rows;			  // rows this rank renders (compact buffer height in use)
+		uint32_t width, height;			   // full frame
+		uint32_t local_rows;			   // rows this rank renders (compact buffer height in use)
 		uint32_t rank, world, stripe_rows; // rt_hip_partition
 		uint32_t samples_per_pixel, max_bounces;
-		uint32_t frame_key;				  // hash of the 64-bit seed
-		float sx, neg_sy;				  // 2/W and -(2/H): ndc = (fma(px, sx, -1), fma(py, neg_sy, 1))
+		uint32_t frame_key;				   // hash of the 64-bit seed
+		float sx, neg_sy;				   // 2/W and -(2/H): ndc = (fma(px, sx, -1), fma(py, neg_sy, 1))
 		// inverse view-projection, pre-split for depth 0 / depth 1 (camera.hpp:42-48):
 		// row_r(depth) = fma(mx[r], ndc.x, fma(my[r], ndc.y, k[r])),  k_near[r] = fma(M[r][2], 0, M[r][3]),
 		// k_far[r] = fma(M[r][2], 1, M[r][3])
 		float mx[4], my[4], k_near[4], k_far[4];
+		// For a camera built as in camera.hpp:122-137 the last row of the inverse view-projection does not depend
+		// on x and y (M[3][0] = M[3][1] = 0), so w is a per-frame constant and 1/w can be taken once on the host.
+		// uniform_w != 0 says so; inv_w_* then hold 1.0f / k_*[3] (bit-identical to the per-sample division).
+		uint32_t uniform_w;
+		float inv_w_near, inv_w_far;
+	};
+
+	// the whole scene of the `small` kernel, passed by value as a kernel argument (-> SGPRs); host copy kept by the context
+	constexpr uint32_t scalar_max_spheres = 8; // sphere-only scenes up to this size run with the scene in SGPRs
+	struct small_scene
+	{
+		float4 geometry[scalar_max_spheres]; // (center, radius^2)
+		float4 shading[scalar_max_spheres];	 // (attenuation.rgb, roughness) of the sphere's material
+		uint32_t metal[scalar_max_spheres];
 	};
 
 	struct device_counters
@@ -49,10 +71,14 @@ namespace rt_hip
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
+	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags);
+
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,
 						   const device_scene& scene,
-						   bool force_tiled,
+						   const small_scene& small, // valid when choose_kernel() says RT_HIP_KERNEL_SMALL
+						   uint32_t flags,
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
@@ -78,4 +104,6 @@ namespace rt_hip
 								float* d_normal,
 								hipStream_t stream);
 	void launch_kat_sqrt_div(uint32_t n, const float* d_a, const float* d_b, float* d_sqrt, float* d_div, hipStream_t stream);
+	// d_result: 3 x { mismatch count (u64), first mismatching input bits (u64) } for sqrt_rn, rcp_rn, inv_sqrt_rn
+	void launch_kat_exhaustive_math(unsigned long long* d_result, hipStream_t stream);
 }

@@ -131,3 +131,11 @@ class HipRayTracer:
         q = np.empty_like(a)
         check(self._lib.rt_hip_kat_sqrt_div(self._ctx, a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data))
         return s, q
+
+    def kat_exhaustive_math(self):
+        """All 2^32 float bit patterns through the kernels' sqrt / reciprocal / reciprocal-sqrt sequences vs the
+        compiler's correctly rounded expansions: ([mismatch counts], [first mismatching input bits])."""
+        counts = (C.c_uint64 * 3)()
+        first = (C.c_uint32 * 3)()
+        check(self._lib.rt_hip_kat_exhaustive_math(self._ctx, C.byref(counts), C.byref(first)))
+        return list(counts), list(first)

@@ -19,6 +19,7 @@ from tests.conftest import GOLDEN, unpack
 pytestmark = pytest.mark.gpu
 
 FORCE_TILED = capi.RT_HIP_FLAG_FORCE_TILED
+FORCE_RESIDENT = capi.RT_HIP_FLAG_FORCE_RESIDENT
 
 
 def assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, what=""):
@@ -54,6 +55,15 @@ def test_device_sqrt_and_division_are_correctly_rounded(tracer):
 
     assert same(gs, ws).all(), f"sqrt differs at {np.nonzero(~same(gs, ws))[0][:5]}"
     assert same(gq, wq).all(), f"division differs at {np.nonzero(~same(gq, wq))[0][:5]}"
+
+
+def test_shortened_sqrt_and_reciprocal_sequences_are_exact_for_every_float(tracer):
+    """The kernels do not use hipcc's general sqrt / division expansions but shorter sequences that are only valid
+    inside an exponent band (with a fallback outside it).  EVERY one of the 2^32 binary32 inputs must give the
+    bit-identical result to the general, correctly rounded expansion — which the test above ties to the CPU."""
+    counts, first = tracer.kat_exhaustive_math()
+    names = ("sqrt_rn", "rcp_rn", "inv_sqrt_rn")
+    assert counts == [0, 0, 0], {n: (c, hex(f)) for n, c, f in zip(names, counts, first)}
 
 
 @pytest.mark.parametrize("seed,pixel,sample", [(1, 0, 0), (1, 12345, 7), (0xDEADBEEFCAFE, 2073599, 255), (2**64 - 1, 2**32 - 1, 999)])
@@ -121,7 +131,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,width,height,spp,bounces,seed", CASES)
-@pytest.mark.parametrize("flags", [0, FORCE_TILED], ids=["auto", "tiled"])
+@pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED], ids=["auto", "resident", "tiled"])
 def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, bounces, seed, flags):
     scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
     scene.set_sampling(spp, bounces)
@@ -132,14 +142,45 @@ def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, boun
     assert stats["segments"] == want_stats["segments"]
     assert stats["primary_samples"] == width * height * spp
     assert stats["sphere_tests"] == want_stats["segments"] * pod.n_spheres
-    expected_kernel = "tiled" if (flags or pod.n_spheres + pod.n_planes > 1024) else "resident"
+    primitives = pod.n_spheres + pod.n_planes
+    if flags == FORCE_TILED or primitives > 1024:
+        expected_kernel = "tiled"
+    elif flags == 0 and pod.n_planes == 0 and 1 <= pod.n_spheres <= 8:
+        expected_kernel = "small"
+    else:
+        expected_kernel = "resident"
     assert stats["kernel"] == expected_kernel
+
+
+def test_projective_matrix_with_varying_w_takes_the_per_sample_division(tracer):
+    """A camera built like the reference's has a constant w per frame (the host takes 1/w once); any other
+    inverse view-projection must go through the per-sample reciprocal and still match the oracle bit for bit."""
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    pod = scene.describe(96, 54)
+    m = np.array(pod.inverse_view_projection[:], dtype=np.float32).reshape(4, 4)
+    m[3, 0], m[3, 1] = 3.0, -2.0  # w now depends on x and y
+    pod.inverse_view_projection = (C.c_float * 16)(*m.reshape(-1))
+    for flags in (0, FORCE_RESIDENT):
+        got_rgba, got_rgb, _ = tracer.render(pod, 96, 54, seed=12, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, _ = oracle.render(pod, 96, 54, seed=12)
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "non-uniform w")
+
+
+@pytest.mark.parametrize("count", [1, 2, 8, 9])
+def test_sphere_counts_around_the_scalar_kernel_limit(tracer, count):
+    scene = rt_amd.Scene.named(f"synthetic-{count}").set_sampling(4)
+    scene.set_camera((0.0, 1.0, 3.0), (0.0, -0.2, -1.0))
+    pod = scene.describe(80, 45)
+    got_rgba, got_rgb, stats = tracer.render(pod, 80, 45, seed=13, want_rgb=True)
+    want_rgba, want_rgb, _ = oracle.render(pod, 80, 45, seed=13)
+    assert stats["kernel"] == ("small" if count <= 8 else "resident")
+    assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{count} spheres")
 
 
 def test_empty_scene_renders_sky(tracer):
     ivp = rt_amd.Scene.named("basic").describe(40, 24).inverse_view_projection[:]
     pod = rt_amd.scene_from_arrays(samples_per_pixel=3, max_bounces=2, inverse_view_projection=ivp)
-    for flags in (0, FORCE_TILED):
+    for flags in (0, FORCE_RESIDENT, FORCE_TILED):
         got_rgba, got_rgb, stats = tracer.render(pod, 40, 24, seed=1, flags=flags, want_rgb=True)
         want_rgba, want_rgb, _ = oracle.render(pod, 40, 24, seed=1)
         assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "empty scene")
@@ -238,7 +279,7 @@ def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
 def test_config2_basic_1080p_64spp(tracer):
     """BASELINE config 2 at full size; the oracle covers 1/8 of the rows (every 8th stripe)."""
     stats = check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(64), 1920, 1080, seed=1, oracle_world=8)
-    assert stats["kernel"] == "resident"
+    assert stats["kernel"] == "small"
 
 
 def test_config3_dielectric_1080p_256spp(tracer):
