@@ -72,19 +72,28 @@ namespace rt_hip
 		return q;
 	}
 
-	// == __builtin_sqrtf(x)
-	__device__ __forceinline__ float sqrt_rn(float x)
+	// The general expansions sit behind a wave-uniform branch that is practically never taken.  The empty asm
+	// statement keeps hipcc from if-converting that branch (it would otherwise evaluate both sides on every call).
+#define RT_HIP_RARE_PATH() asm volatile("; rare path: general IEEE expansion" ::: "memory")
+
+	// == __builtin_sqrtf(x) in every lane where `wanted` holds (other lanes get an unspecified finite value)
+	__device__ __forceinline__ float sqrt_rn_where(float x, bool wanted)
 	{
 		const bool fast = in_fast_band(x);
 		float h;
 		float s = sqrt_core(fast ? x : 1.0f, h);
-		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		const bool general = wanted && !fast; // 0, subnormal, huge, infinite, negative or NaN
+		if (__builtin_amdgcn_ballot_w64(general) != 0)
 		{
-			const float general = __builtin_sqrtf(x);
-			s = fast ? s : general;
+			RT_HIP_RARE_PATH();
+			const float g = __builtin_sqrtf(x);
+			s = general ? g : s;
 		}
 		return s;
 	}
+
+	// == __builtin_sqrtf(x)
+	__device__ __forceinline__ float sqrt_rn(float x) { return sqrt_rn_where(x, true); }
 
 	// == 1.0f / x
 	__device__ __forceinline__ float rcp_rn(float x)
@@ -94,8 +103,9 @@ namespace rt_hip
 		float q = rcp_core(xs, __builtin_amdgcn_rcpf(xs));
 		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
 		{
-			const float general = 1.0f / x;
-			q = fast ? q : general;
+			RT_HIP_RARE_PATH();
+			const float g = 1.0f / x;
+			q = fast ? q : g;
 		}
 		return q;
 	}
@@ -112,8 +122,9 @@ namespace rt_hip
 		float q = rcp_core(s, __builtin_amdgcn_rcpf(s));
 		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
 		{
-			const float general = 1.0f / __builtin_sqrtf(x);
-			q = fast ? q : general;
+			RT_HIP_RARE_PATH();
+			const float g = 1.0f / __builtin_sqrtf(x);
+			q = fast ? q : g;
 		}
 		return q;
 	}

@@ -55,7 +55,7 @@ namespace rt_hip
 			const bool pos = !(disc < 0.0f); // hits_sphere: `if (disc < 0) return nullopt`
 			if (__builtin_amdgcn_ballot_w64(pos) != 0) // no lane can hit: skip the square root for the whole wave
 			{
-				const float f = sqrt_rn(pos ? disc : 1.0f);
+				const float f = sqrt_rn_where(disc, pos); // lanes with disc < 0 never use f
 				const float t = (e2 < s.w) ? a + f : a - f;
 				// hits() holds a value <=> pos && !(t < 0); the scan then drops t < min_hit_dist (which covers
 				// t < 0) and anything not closer than the best so far: `hit_index && hit_dist <= *hit` (:74)
