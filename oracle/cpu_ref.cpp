@@ -27,6 +27,11 @@
 //   lerp(a,b,t)       = fmaf(b - a, t, a) per component
 //   transform_position(M,v): row_r = fmaf(M[r][0],v.x, fmaf(M[r][1],v.y, fmaf(M[r][2],v.z, M[r][3])));
 //                            xyz = row_0..2 * (1.0f / row_3)
+//   pixel sum               : samples are added in CHUNKS of 16 consecutive samples (each chunk summed in sample
+//                            order, starting from 0), and the chunk sums are added in chunk order (left fold starting
+//                            from the first chunk's sum).  For spp <= 16 this is the reference's plain sequential
+//                            `colour += trace(...)` (mg_ray_tracer.cpp:187-194); for larger spp it is the same sum
+//                            associated differently — the unit of work a GPU lane takes is one chunk.
 //   everything else is written out where it is used.
 //
 // Build: -O2 -ffp-contract=off (no -ffast-math); -mfma only makes fmaf() a single instruction.
@@ -196,6 +201,7 @@ namespace
 
 	// ---- intersection (muu::ray::hits; formulas per SURVEY.md §8c) ------------------------------------------------
 	constexpr float min_hit_dist = 0.001f; // mg_ray_tracer.cpp:20
+	constexpr uint32_t sample_chunk = 16;  // samples per chunk of the pixel sum (arithmetic contract)
 	constexpr float approx_zero_epsilon = 1.0e-6f;
 
 	// returns false = no hit (std::nullopt in muu)
@@ -416,6 +422,7 @@ namespace
 		const rt_hip_scene& s = *f.scene;
 		const uint32_t pixel_index = y * f.width + x; // image_view::position_of inverse, src/image.hpp:155-159
 		vec3 colour = { 0, 0, 0 };
+		vec3 chunk = { 0, 0, 0 };
 		for (uint32_t i = 0, e = s.samples_per_pixel; i < e; i++)
 		{
 			random_stream rng{ f.frame_key, pixel_index, i };
@@ -430,7 +437,12 @@ namespace
 			const ray r = primary_ray(f, px, py);
 			const vec3 sample = f.trace_order == ORACLE_TRACE_RECURSIVE ? trace_recursive(f, r, s.max_bounces, rng, c)
 																		 : trace_iterative(f, r, s.max_bounces, rng, c);
-			colour = colour + sample;
+			chunk = chunk + sample;
+			if ((i + 1) % sample_chunk == 0 || i + 1 == e) // end of a chunk of 16 samples
+			{
+				colour = (i < sample_chunk) ? chunk : colour + chunk;
+				chunk = { 0, 0, 0 };
+			}
 		}
 		const float n = static_cast<float>(s.samples_per_pixel);
 		colour = { colour.x / n, colour.y / n, colour.z / n }; // :195

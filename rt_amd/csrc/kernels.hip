@@ -139,11 +139,12 @@ namespace rt_hip
 		{
 			vec3 origin, dir;	// current ray
 			vec3 throughput;	// product of attenuations so far (trace unrolled front to back)
-			vec3 colour;		// running sum over samples (:186,193)
+			vec3 chunk_sum;		// running sum of the chunk of samples in flight (:186,193)
 			float fx, fy;		// pixel coordinates as floats
 			uint32_t pixel_key; // random stream key of the pixel
 			uint32_t counter;	// random stream position
 			uint32_t sample;	// index of the sample in flight
+			uint32_t sample_end; // one past the last sample of the chunk in flight
 			uint32_t bounces_left;
 			uint32_t segments;
 		};
@@ -228,34 +229,11 @@ namespace rt_hip
 			return ((local_row / p.stripe_rows) * p.world + p.rank) * p.stripe_rows + (local_row % p.stripe_rows);
 		}
 
-		// Pixel owned by this lane; false if outside this rank's part of the frame.  Workgroups are handed out
-		// bottom row first: the lower part of a frame is usually the expensive one (ground under sky), and starting
-		// with it keeps the cheap sky tiles for the tail of the launch.
-		__device__ __forceinline__ bool lane_pixel(const frame_params& p, uint32_t& lx, uint32_t& ly)
-		{
-			const uint32_t lane = threadIdx.x & 63u;
-			const uint32_t wave = threadIdx.x >> 6;
-			lx = blockIdx.x * block_pixels_x + wave * 8u + (lane & 7u);
-			ly = (gridDim.y - 1u - blockIdx.y) * block_pixels_y + (lane >> 3);
-			return lx < p.width && ly < p.local_rows;
-		}
-
-		__device__ __forceinline__ void init_lane(lane_state& st, const frame_params& p, uint32_t lx, uint32_t ly)
-		{
-			const uint32_t gy = global_row(ly, p);
-			st.fx = static_cast<float>(lx);
-			st.fy = static_cast<float>(gy);
-			st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
-			st.colour = { 0.0f, 0.0f, 0.0f };
-			st.sample = 0;
-			st.segments = 0;
-		}
-
 		// :195-200 — mean, sqrt "gamma", pack, store
-		__device__ __forceinline__ void finish_pixel(const lane_state& st, const frame_params& p, uint32_t lx, uint32_t ly, uint32_t* out_rgba, float* out_rgb)
+		__device__ __forceinline__ void finish_pixel(vec3 colour, const frame_params& p, uint32_t lx, uint32_t ly, uint32_t* out_rgba, float* out_rgb)
 		{
 			const float n = static_cast<float>(p.samples_per_pixel);
-			const vec3 mean = { st.colour.x / n, st.colour.y / n, st.colour.z / n };
+			const vec3 mean = { colour.x / n, colour.y / n, colour.z / n };
 			const size_t o = static_cast<size_t>(ly) * p.width + lx;
 			if (out_rgb)
 			{
@@ -276,72 +254,7 @@ namespace rt_hip
 				atomicAdd(&counters->segments, total);
 		}
 
-		// ---- small kernel: <= 8 spheres, no planes; the scene is a kernel argument ----------------------------------
-		template <int NS>
-		__global__ __launch_bounds__(block_threads) void render_small(const frame_params p,
-																	  const small_scene scene,
-																	  uint32_t* __restrict__ out_rgba,
-																	  float* __restrict__ out_rgb,
-																	  device_counters* __restrict__ counters)
-		{
-			// per-lane lookups of the winning sphere (its index differs from lane to lane) go through LDS
-			__shared__ float4 lds_geometry[scalar_max_spheres];
-			__shared__ float4 lds_shading[scalar_max_spheres];
-			__shared__ uint32_t lds_metal[scalar_max_spheres];
-			if (threadIdx.x == 0)
-			{
-#pragma unroll
-				for (int i = 0; i < NS; i++) // constant indices: the argument block is never indexed dynamically
-				{
-					lds_geometry[i] = scene.geometry[i];
-					lds_shading[i] = scene.shading[i];
-					lds_metal[i] = scene.metal[i];
-				}
-			}
-			__syncthreads();
-
-			uint32_t lx, ly;
-			lane_state st;
-			st.segments = 0;
-			if (lane_pixel(p, lx, ly))
-			{
-				init_lane(st, p, lx, ly);
-				start_sample(st, p);
-				while (true)
-				{
-					st.bounces_left--;
-					st.segments++;
-					candidate best = { 0.0f, 0u, false };
-#pragma unroll
-					for (int i = 0; i < NS; i++)
-						test_sphere(best, st.origin, st.dir, scene.geometry[i], static_cast<uint32_t>(i)); // SGPR operands
-					const bool hit = best.have && best.t >= 0.0f;
-					vec3 normal = { 0.0f, 0.0f, 0.0f };
-					float4 shading = { 0.0f, 0.0f, 0.0f, 0.0f };
-					bool metal = false;
-					if (hit)
-					{
-						const float4 g = lds_geometry[best.index];
-						shading = lds_shading[best.index];
-						metal = lds_metal[best.index] != 0;
-						// vec3::direction(center, r.at(t)) (:85)
-						normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z });
-					}
-					vec3 contribution;
-					if (shade_segment(st, hit ? 1u : 0u, best.t, normal, shading, metal, contribution))
-					{
-						st.colour = st.colour + contribution;
-						if (++st.sample >= p.samples_per_pixel)
-							break;
-						start_sample(st, p);
-					}
-				}
-				finish_pixel(st, p, lx, ly, out_rgba, out_rgb);
-			}
-			add_segments(counters, st.segments);
-		}
-
-		// lookups of the winning primitive for the LDS kernels (global tables; one indexed read each)
+		// lookups of the winning primitive from the global per-primitive tables (one indexed read each)
 		__device__ __forceinline__ void
 		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, bool& metal)
 		{
@@ -361,57 +274,198 @@ namespace rt_hip
 			}
 		}
 
-		// ---- resident kernel ------------------------------------------------------------------------------------
-		__global__ __launch_bounds__(block_threads) void render_resident(const frame_params p,
-																		 const device_scene s,
-																		 uint32_t* __restrict__ out_rgba,
-																		 float* __restrict__ out_rgb,
-																		 device_counters* __restrict__ counters)
+		// ---- small / resident kernel: a wave works through a queue of (pixel, sample chunk) items -----------------------
+		//
+		// The pixel sum is defined chunk-wise (arithmetic contract: chunks of 16 consecutive samples, each summed in
+		// sample order, chunk sums added in chunk order).  That makes ONE CHUNK the unit of work: a wave owns a small
+		// tile of P pixels = P x K items (K = chunks per pixel); its 64 lanes pull items from the wave's queue as they
+		// finish the previous one, park every chunk sum in a wave-private LDS slot, and at the end P lanes fold the
+		// slots in chunk order and write the pixels.  Short items keep every lane busy until the queue is empty and
+		// keep waves short, so that a launch has tens of thousands of them to balance over the chip; which lane
+		// computes which chunk cannot change a result.
+		//
+		// NS > 0: `small` kernel, NS spheres in SGPRs (kernel argument).  NS == 0: `resident` kernel, primitives in LDS.
+		template <int NS>
+		__global__ __launch_bounds__(block_threads) void render_queue(const frame_params p,
+																	  const queue_params q,
+																	  const small_scene small,
+																	  const device_scene s,
+																	  uint32_t* __restrict__ out_rgba,
+																	  float* __restrict__ out_rgb,
+																	  device_counters* __restrict__ counters)
 		{
 			extern __shared__ float4 lds[];
-			float4* const lds_spheres = lds;
-			float4* const lds_planes = lds + s.n_spheres;
-			for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
-				lds[i] = s.primitive_geometry[i];
+			// [NS > 0] 8 geometry + 8 shading float4s, 8 metal flags | [NS == 0] all primitives; then the chunk slots
+			float4* const lds_geometry = lds;
+			float4* const lds_shading = lds + scalar_max_spheres;
+			uint32_t* const lds_metal = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
+			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (s.n_spheres + s.n_planes);
+			if (NS > 0)
+			{
+				if (threadIdx.x == 0)
+				{
+#pragma unroll
+					for (int i = 0; i < NS; i++) // constant indices: the argument block is never indexed dynamically
+					{
+						lds_geometry[i] = small.geometry[i];
+						lds_shading[i] = small.shading[i];
+						lds_metal[i] = small.metal[i];
+					}
+				}
+			}
+			else
+			{
+				for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
+					lds[i] = s.primitive_geometry[i];
+			}
 			__syncthreads();
 
-			uint32_t lx, ly;
+			const uint32_t lane = threadIdx.x & 63u;
+			const uint32_t wave = threadIdx.x >> 6;
+			const uint32_t items = q.chunks << q.pixels_log2; // P x K
+			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * items * 3u;
+
+			// this wave's pixel tile; workgroups are handed out bottom row first: the lower part of a frame is usually
+			// the expensive one (ground under sky), and starting with it keeps the cheap sky tiles for the tail
+			const uint32_t tile_w = 1u << q.tile_w_log2;
+			const uint32_t tile_h = (1u << q.pixels_log2) >> q.tile_w_log2;
+			const uint32_t tile_x0 = (blockIdx.x * 4u + wave) * tile_w;
+			const uint32_t tile_y0 = (gridDim.y - 1u - blockIdx.y) * tile_h;
+
 			lane_state st;
 			st.segments = 0;
-			if (lane_pixel(p, lx, ly))
+			uint32_t next_item = 0;	 // wave-uniform queue head
+			uint32_t item = 0;		 // item in flight on this lane
+			bool want_item = true;	 // lane is free
+			bool retired = false;	 // queue ran dry for this lane
+
+			while (true)
 			{
-				init_lane(st, p, lx, ly);
-				start_sample(st, p);
-				while (true)
+				// ---- hand out items to free lanes (converged) ---------------------------------------------------------
+				const unsigned long long asking = __builtin_amdgcn_ballot_w64(want_item);
+				if (asking != 0)
+				{
+					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
+					if (want_item)
+					{
+						item = next_item + rank;
+						if (item >= items)
+						{
+							retired = true;
+							want_item = false;
+						}
+						else
+						{
+							const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
+							const uint32_t chunk = item >> q.pixels_log2;
+							const uint32_t lx = tile_x0 + (pixel & (tile_w - 1u));
+							const uint32_t ly = tile_y0 + (pixel >> q.tile_w_log2);
+							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+							if (lx < p.width && ly < p.local_rows)
+							{
+								const uint32_t gy = global_row(ly, p);
+								st.fx = static_cast<float>(lx);
+								st.fy = static_cast<float>(gy);
+								st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+								st.sample = chunk * sample_chunk;
+								st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+								start_sample(st, p);
+								want_item = false;
+							}
+							// else: a pixel outside the frame — the item is empty, ask again next trip
+						}
+					}
+					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
+				}
+				if (__builtin_amdgcn_ballot_w64(!retired) == 0)
+					break;
+
+				// ---- one path segment for every lane that holds an item --------------------------------------------------
+				if (!retired && !want_item)
 				{
 					st.bounces_left--;
 					st.segments++;
-					candidate planes = { 0.0f, 0u, false };
-					candidate spheres = { 0.0f, 0u, false };
-					scan_lds<false>(planes, st.origin, st.dir, lds_planes, s.n_planes, 0);
-					scan_lds<true>(spheres, st.origin, st.dir, lds_spheres, s.n_spheres, 0);
+					uint32_t kind;
 					float distance;
-					uint32_t index;
-					const uint32_t kind = select_hit(spheres, planes, distance, index);
-					vec3 normal;
-					float4 shading;
-					bool metal;
-					fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+					vec3 normal = { 0.0f, 0.0f, 0.0f };
+					float4 shading = { 0.0f, 0.0f, 0.0f, 0.0f };
+					bool metal = false;
+					if (NS > 0)
+					{
+						candidate best = { 0.0f, 0u, false };
+#pragma unroll
+						for (int i = 0; i < NS; i++)
+							test_sphere(best, st.origin, st.dir, small.geometry[i], static_cast<uint32_t>(i)); // SGPR operands
+						const bool hit = best.have && best.t >= 0.0f;
+						kind = hit ? 1u : 0u;
+						distance = best.t;
+						if (hit)
+						{
+							const float4 g = lds_geometry[best.index];
+							shading = lds_shading[best.index];
+							metal = lds_metal[best.index] != 0;
+							normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z }); // (:85)
+						}
+					}
+					else
+					{
+						candidate planes = { 0.0f, 0u, false };
+						candidate spheres = { 0.0f, 0u, false };
+						scan_lds<false>(planes, st.origin, st.dir, lds + s.n_spheres, s.n_planes, 0);
+						scan_lds<true>(spheres, st.origin, st.dir, lds, s.n_spheres, 0);
+						uint32_t index;
+						kind = select_hit(spheres, planes, distance, index);
+						fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+					}
 					vec3 contribution;
 					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
 					{
-						st.colour = st.colour + contribution;
-						if (++st.sample >= p.samples_per_pixel)
-							break;
-						start_sample(st, p);
+						st.chunk_sum = st.chunk_sum + contribution;
+						if (++st.sample < st.sample_end)
+							start_sample(st, p);
+						else
+						{
+							slots[item * 3u + 0u] = st.chunk_sum.x;
+							slots[item * 3u + 1u] = st.chunk_sum.y;
+							slots[item * 3u + 2u] = st.chunk_sum.z;
+							want_item = true;
+						}
 					}
 				}
-				finish_pixel(st, p, lx, ly, out_rgba, out_rgb);
+			}
+
+			// ---- fold the chunk sums of each pixel in chunk order and write the pixel (:195-200) ------------------------------
+			__syncthreads();
+			if (lane < (1u << q.pixels_log2))
+			{
+				const uint32_t lx = tile_x0 + (lane & (tile_w - 1u));
+				const uint32_t ly = tile_y0 + (lane >> q.tile_w_log2);
+				if (lx < p.width && ly < p.local_rows)
+				{
+					vec3 colour = { slots[lane * 3u], slots[lane * 3u + 1u], slots[lane * 3u + 2u] };
+					for (uint32_t c = 1; c < q.chunks; c++)
+					{
+						const uint32_t slot = ((c << q.pixels_log2) + lane) * 3u;
+						colour = colour + vec3{ slots[slot], slots[slot + 1u], slots[slot + 2u] };
+					}
+					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+				}
 			}
 			add_segments(counters, st.segments);
 		}
 
 		// ---- tiled kernel -----------------------------------------------------------------------------------------
+		// one lane = one pixel, all of its samples in order (the chunk sums are folded as they complete); the
+		// workgroup advances in lock step, one path segment per trip, streaming the primitives through LDS
+		__device__ __forceinline__ bool lane_pixel(const frame_params& p, uint32_t& lx, uint32_t& ly)
+		{
+			const uint32_t lane = threadIdx.x & 63u;
+			const uint32_t wave = threadIdx.x >> 6;
+			lx = blockIdx.x * block_pixels_x + wave * 8u + (lane & 7u);
+			ly = (gridDim.y - 1u - blockIdx.y) * block_pixels_y + (lane >> 3);
+			return lx < p.width && ly < p.local_rows;
+		}
+
 		__global__ __launch_bounds__(block_threads) void render_tiled(const frame_params p,
 																	  const device_scene s,
 																	  uint32_t* __restrict__ out_rgba,
@@ -423,10 +477,17 @@ namespace rt_hip
 			uint32_t lx, ly;
 			lane_state st;
 			st.segments = 0;
+			vec3 colour = { 0.0f, 0.0f, 0.0f };
 			bool alive = lane_pixel(p, lx, ly);
 			if (alive)
 			{
-				init_lane(st, p, lx, ly);
+				const uint32_t gy = global_row(ly, p);
+				st.fx = static_cast<float>(lx);
+				st.fy = static_cast<float>(gy);
+				st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx);
+				st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+				st.sample = 0;
+				st.sample_end = min(sample_chunk, p.samples_per_pixel);
 				start_sample(st, p);
 			}
 
@@ -469,11 +530,17 @@ namespace rt_hip
 					vec3 contribution;
 					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
 					{
-						st.colour = st.colour + contribution;
-						if (++st.sample >= p.samples_per_pixel)
+						st.chunk_sum = st.chunk_sum + contribution;
+						if (++st.sample >= st.sample_end) // chunk complete: fold it (the first chunk IS the running total)
+						{
+							colour = st.sample <= sample_chunk ? st.chunk_sum : colour + st.chunk_sum;
+							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+							st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+						}
+						if (st.sample >= p.samples_per_pixel)
 						{
 							alive = false;
-							finish_pixel(st, p, lx, ly, out_rgba, out_rgb);
+							finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
 						}
 						else
 							start_sample(st, p);
@@ -616,9 +683,18 @@ namespace rt_hip
 		}
 
 		template <int NS>
-		void launch_small(const frame_params& frame, const small_scene& scene, dim3 grid, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream)
+		void launch_queue(const frame_params& frame,
+						  const queue_params& queue,
+						  const small_scene& small,
+						  const device_scene& scene,
+						  dim3 grid,
+						  size_t lds_bytes,
+						  uint32_t* d_rgba8,
+						  float* d_rgb_f32,
+						  device_counters* d_counters,
+						  hipStream_t stream)
 		{
-			hipLaunchKernelGGL(render_small<NS>, grid, dim3(block_threads), 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
+			hipLaunchKernelGGL(render_queue<NS>, grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, d_rgba8, d_rgb_f32, d_counters);
 		}
 	}
 
@@ -634,6 +710,19 @@ namespace rt_hip
 		return RT_HIP_KERNEL_TILED;
 	}
 
+	queue_params choose_queue(uint32_t samples_per_pixel)
+	{
+		// K chunks per pixel; P pixels per wave so that a wave's queue holds about 256 items (4 per lane)
+		queue_params q{};
+		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk;
+		uint32_t pixels_log2 = 6; // 64 pixels = 8 x 8
+		while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
+			pixels_log2--;
+		q.pixels_log2 = pixels_log2;
+		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 8x8, 8x4, 4x4, 4x2, 2x2
+		return q;
+	}
+
 	uint32_t launch_render(const frame_params& frame,
 						   const device_scene& scene,
 						   const small_scene& small,
@@ -643,35 +732,38 @@ namespace rt_hip
 						   device_counters* d_counters,
 						   hipStream_t stream)
 	{
-		const dim3 grid((frame.width + block_pixels_x - 1) / block_pixels_x, (frame.local_rows + block_pixels_y - 1) / block_pixels_y);
-		const dim3 block(block_threads);
-		if (!grid.x || !grid.y)
+		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
+		if (variant == RT_HIP_KERNEL_TILED)
+		{
+			const dim3 grid((frame.width + block_pixels_x - 1) / block_pixels_x, (frame.local_rows + block_pixels_y - 1) / block_pixels_y);
+			hipLaunchKernelGGL(render_tiled, grid, dim3(block_threads), 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
+			return variant;
+		}
+		const queue_params queue = choose_queue(frame.samples_per_pixel);
+		const uint32_t tile_w = 1u << queue.tile_w_log2;
+		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
+		const dim3 grid((frame.width + 4u * tile_w - 1u) / (4u * tile_w), (frame.local_rows + tile_h - 1u) / tile_h);
+		const size_t slot_bytes = static_cast<size_t>(block_threads / 64u) * (queue.chunks << queue.pixels_log2) * 3u * sizeof(float);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
-			const small_scene& args = small;
+			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
 			switch (scene.n_spheres)
 			{
-				case 1: launch_small<1>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 2: launch_small<2>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 3: launch_small<3>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 4: launch_small<4>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 5: launch_small<5>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 6: launch_small<6>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 7: launch_small<7>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				default: launch_small<8>(frame, args, grid, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 1: launch_queue<1>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 2: launch_queue<2>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 3: launch_queue<3>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 4: launch_queue<4>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 5: launch_queue<5>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 6: launch_queue<6>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 7: launch_queue<7>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				default: launch_queue<8>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
 			}
 			return variant;
 		}
-		if (variant == RT_HIP_KERNEL_RESIDENT)
-		{
-			const uint32_t primitives = scene.n_spheres + scene.n_planes;
-			const size_t lds_bytes = static_cast<size_t>(primitives ? primitives : 1u) * sizeof(float4);
-			hipLaunchKernelGGL(render_resident, grid, block, lds_bytes, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
-			return variant;
-		}
-		hipLaunchKernelGGL(render_tiled, grid, block, 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
+		const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
+		launch_queue<0>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 		return variant;
 	}
 

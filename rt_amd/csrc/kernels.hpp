@@ -63,6 +63,18 @@ namespace rt_hip
 		uint32_t metal[scalar_max_spheres];
 	};
 
+	// pixel sums are taken in chunks of this many consecutive samples (arithmetic contract; see oracle/cpu_ref.cpp)
+	constexpr uint32_t sample_chunk = 16;
+
+	// shape of the per-wave work queue of the small / resident kernels
+	struct queue_params
+	{
+		uint32_t chunks;	  // K: sample chunks per pixel = ceil(spp / sample_chunk)
+		uint32_t pixels_log2; // a wave owns P = 2^pixels_log2 pixels (a tile of 2^tile_w_log2 columns)
+		uint32_t tile_w_log2;
+	};
+	queue_params choose_queue(uint32_t samples_per_pixel);
+
 	struct device_counters
 	{
 		unsigned long long segments;
