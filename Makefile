@@ -15,7 +15,7 @@ HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp include/rt_hip.h
 HOST_SRC := rt_amd/host/host_capi.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
 HOST_HDR := $(wildcard rt_amd/host/*.hpp) rt_amd/host/host_capi.h rt_amd/host/named_colours.inc include/rt_hip.h
 
-all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so oracle
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so rt_amd/bin/rt_headless oracle
 
 $(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
@@ -25,11 +25,18 @@ $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC)
 
+# windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
+HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/renderer.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/null_renderer.cpp \
+                rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
+rt_amd/bin/rt_headless: $(HEADLESS_SRC) $(HOST_HDR) $(LIBDIR)/librt_hip.so
+	@mkdir -p rt_amd/bin
+	$(CXX) $(HOSTFLAGS) -o $@ $(HEADLESS_SRC) -L$(LIBDIR) -lrt_hip -Wl,-rpath,'$$ORIGIN/../lib'
+
 oracle:
 	$(MAKE) -C oracle
 
 clean:
-	rm -f $(LIBDIR)/*.so
+	rm -f $(LIBDIR)/*.so rt_amd/bin/rt_headless
 	$(MAKE) -C oracle clean
 
 .PHONY: all oracle clean

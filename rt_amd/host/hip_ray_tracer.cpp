@@ -1,0 +1,85 @@
+// rt_amd/host/hip_ray_tracer.cpp — the MI355X renderer as an rt plug-in.
+//
+// This is the whole of the reference-side code the path needs: a renderer_interface implementation that gathers
+// the scene's struct-of-arrays column pointers and the camera matrix into the POD rt_hip_scene and calls the C ABI
+// (include/rt_hip.h).  shim/hip_ray_tracer.cpp is the same file written against the REAL rt/muu headers
+// (INTEGRATION.md); this copy compiles against the mirror in rt_amd/host so that it can be built and run here.
+//
+// Behaviour at the boundary:
+//   - registered with REGISTER_RENDERER like every rt renderer; selectable as `--renderer hip`;
+//   - the rt_hip context is created lazily on the first render() and destroyed with the renderer object;
+//   - render() is noexcept and returns void: on any failure it prints `error: ...` to stderr (the reference's
+//     style, src/main.cpp:43-47) and leaves the caller's pre-cleared frame (src/main.cpp:318) untouched;
+//   - the passed thread pool is ignored; the call blocks until the frame is in `pixels`.
+#include "renderer.hpp"
+
+#include "../../include/rt_hip.h"
+
+#include <atomic>
+#include <cstdlib>
+#include <iostream>
+
+using namespace rt;
+
+namespace
+{
+	struct hip_ray_tracer final : renderer_interface
+	{
+		rt_hip_ctx* ctx = nullptr;
+		bool failed_to_create = false;
+		uint64_t frame_number = 0;
+
+		~hip_ray_tracer() noexcept override { rt_hip_destroy(ctx); }
+
+		void render(const rt::scene& scene, image_view& pixels, muu::thread_pool& /*threads*/) noexcept override
+		{
+			if (!pixels || failed_to_create)
+				return;
+			if (!ctx)
+			{
+				const char* device = std::getenv("RT_HIP_DEVICE");
+				if (rt_hip_create(&ctx, device ? std::atoi(device) : 0) != RT_HIP_OK)
+				{
+					std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+					failed_to_create = true;
+					return;
+				}
+			}
+
+			rt_hip_scene s{};
+			s.n_spheres = static_cast<uint32_t>(scene.spheres.size());
+			s.sphere_center_x = scene.spheres.center_x();
+			s.sphere_center_y = scene.spheres.center_y();
+			s.sphere_center_z = scene.spheres.center_z();
+			s.sphere_radius = scene.spheres.radius();
+			s.sphere_material = scene.spheres.material();
+			s.n_planes = static_cast<uint32_t>(scene.planes.size());
+			s.plane_normal_x = scene.planes.normal_x();
+			s.plane_normal_y = scene.planes.normal_y();
+			s.plane_normal_z = scene.planes.normal_z();
+			s.plane_d = scene.planes.d();
+			s.plane_material = scene.planes.material();
+			s.n_materials = static_cast<uint32_t>(scene.materials.size());
+			s.material_type = reinterpret_cast<const uint32_t*>(scene.materials.type());
+			s.material_albedo = reinterpret_cast<const float*>(scene.materials.albedo());
+			s.material_roughness = scene.materials.roughness();
+			s.material_reflectivity = scene.materials.reflectivity();
+			s.samples_per_pixel = scene.samples_per_pixel;
+			s.max_bounces = scene.max_bounces;
+			const auto view = scene.camera.viewport(pixels.size()); // mg_ray_tracer.cpp:180
+			for (size_t r = 0; r < 4; r++)
+				for (size_t c = 0; c < 4; c++)
+					s.inverse_view_projection[r * 4 + c] = view.inverse_view_projection(r, c);
+
+			// The reference draws fresh random numbers every frame (src/random.cpp:12-13): a new seed per frame keeps
+			// that behaviour; RT_HIP_SEED pins it for reproducible output.
+			const char* fixed = std::getenv("RT_HIP_SEED");
+			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
+
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, RT_HIP_FLAG_NONE, nullptr, nullptr) != RT_HIP_OK)
+				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+		}
+	};
+
+	REGISTER_RENDERER(hip_ray_tracer);
+}

@@ -1,0 +1,67 @@
+// rt_amd/host/renderer.hpp — the renderer plug-in interface and registry, mirroring reference src/renderer.hpp.
+//
+// renderer_interface::render(const scene&, image_view&, thread_pool&) noexcept is THE drop-in boundary of the path
+// (reference src/renderer.hpp:9-14); REGISTER_RENDERER(T) installs {key, name, create} from a static initialiser
+// (:34-41) into a function-local registry with de-duplication by key (reference src/renderer.cpp:11-37).
+#pragma once
+
+#include "image.hpp"
+#include "scene.hpp"
+
+#include <span>
+#include <string_view>
+
+namespace muu
+{
+	// stand-in for muu::thread_pool (reference src/main.cpp:165): the GPU renderer receives it and ignores it
+	// (SURVEY.md §8b "Threading"); CPU renderers built against this mirror may use for_range.
+	class thread_pool
+	{
+	  public:
+		template <typename T, typename F>
+		void for_range(T begin, T end, F&& worker)
+		{
+			for (T i = begin; i < end; i++)
+				worker(i);
+		}
+		void wait() noexcept {}
+	};
+}
+
+namespace rt
+{
+	struct renderer_interface
+	{
+		virtual void render(const scene&, image_view&, muu::thread_pool&) noexcept = 0;
+		virtual ~renderer_interface() noexcept = default;
+	};
+
+	namespace renderers
+	{
+		struct description
+		{
+			using create_func = renderer_interface*();
+
+			std::string_view key;
+			std::string_view name;
+			create_func* create;
+		};
+
+		void install(const description& desc);
+		std::span<const description> all() noexcept;
+		const description* find_by_key(std::string_view) noexcept;
+		const description* find_by_name(std::string_view) noexcept;
+	}
+}
+
+#define RT_HOST_STRINGIFY_2(x) #x
+#define RT_HOST_STRINGIFY(x)   RT_HOST_STRINGIFY_2(x)
+#define RT_HOST_CONCAT_2(a, b) a##b
+#define RT_HOST_CONCAT(a, b)   RT_HOST_CONCAT_2(a, b)
+
+#define REGISTER_RENDERER(T)                                                                                           \
+	static const int RT_HOST_CONCAT(register_val_impl_, __LINE__) =                                                    \
+		(::rt::renderers::install({ .key = __FILE__ ":" RT_HOST_STRINGIFY(__LINE__) ":" RT_HOST_STRINGIFY(T),            \
+									.name = RT_HOST_STRINGIFY(T),                                                      \
+									.create = []() -> ::rt::renderer_interface* { return new T; } }),                  \
+		 0)

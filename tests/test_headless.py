@@ -1,0 +1,53 @@
+"""rt_headless (rt_amd/host/main.cpp): the windowless driver around the renderer registry and the hip_ray_tracer
+plug-in — the C++ host side a user of the reference would run."""
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import ROOT
+
+BIN = ROOT / "rt_amd" / "bin" / "rt_headless"
+
+
+def run(*args, **kw):
+    return subprocess.run([str(BIN), *args], cwd=ROOT, capture_output=True, text=True, timeout=300, **kw)
+
+
+def test_list_shows_the_registered_renderers():
+    out = run("--list")
+    assert out.returncode == 0
+    assert "hip_ray_tracer" in out.stdout and "null_renderer" in out.stdout
+
+
+def test_unknown_renderer_and_missing_scene_fail_like_the_reference():
+    out = run("--renderer", "vulkan")
+    assert out.returncode == 1 and "error: no known renderer with name 'vulkan'" in out.stderr
+    out = run("--renderer", "null", "--scene", "nope.toml")
+    assert out.returncode == 1 and "did not exist or was not a file" in out.stderr
+
+
+def test_prefix_match_and_null_renderer_leave_the_cleared_frame(tmp_path):
+    ppm = tmp_path / "black.ppm"
+    out = run("--renderer", "null", "--scene", "basic.toml", "--size", "16x8", "--out", str(ppm))
+    assert out.returncode == 0 and "created renderer: null_renderer" in out.stdout
+    data = ppm.read_bytes()
+    assert data.startswith(b"P6\n16 8\n255\n") and set(data[len(b"P6\n16 8\n255\n") :]) == {0}
+
+
+@pytest.mark.gpu
+def test_hip_ray_tracer_plugin_renders_the_oracle_frame(tmp_path):
+    import rt_amd
+    from oracle import binding as oracle
+    from tests.conftest import unpack
+
+    ppm = tmp_path / "frame.ppm"
+    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "96x54", "--spp", "5", "--seed", "11", "--out", str(ppm))
+    assert out.returncode == 0, out.stderr
+    assert "error:" not in out.stderr
+    header = b"P6\n96 54\n255\n"
+    data = ppm.read_bytes()
+    got = np.frombuffer(data[len(header) :], dtype=np.uint8).reshape(54, 96, 3)
+    scene = rt_amd.Scene.named("basic").set_sampling(5)
+    want, _, _ = oracle.render(scene.describe(96, 54), 96, 54, seed=11, want_rgb=False)
+    assert np.array_equal(got, unpack(want)[..., :3])
