@@ -1,0 +1,91 @@
+// shim/hip_ray_tracer.cpp — the reference-side binding of the MI355X renderer module.
+//
+// Drop this file into marzer/rt's src/renderers/, add it to src/renderers/meson.build next to mg_ray_tracer.cpp
+// (reference src/renderers/meson.build:7-12), put include/rt_hip.h on the include path and link librt_hip.so
+// (see INTEGRATION.md).  It is the only code that sees rt / muu types; everything below it is plain C.
+//
+// It cannot be compiled in this repository: rt's headers pull in marzer/muu, which is a network-fetched meson
+// wrap (reference subprojects/muu.wrap).  rt_amd/host/hip_ray_tracer.cpp is the same logic compiled and tested
+// against a mirror of the rt interfaces (tests/test_headless.py).
+//
+// Replaces: mg_ray_tracer::render (reference src/renderers/mg_ray_tracer.cpp:178-205) behind
+// renderer_interface::render (reference src/renderer.hpp:9-14).
+#include "../scene.hpp"
+#include "../image.hpp"
+#include "../renderer.hpp"
+MUU_DISABLE_WARNINGS;
+#include <muu/thread_pool.h>
+#include <cstdlib>
+#include <iostream>
+#include <rt_hip.h>
+MUU_ENABLE_WARNINGS;
+
+using namespace rt;
+
+namespace
+{
+	struct hip_ray_tracer final : renderer_interface
+	{
+		rt_hip_ctx* ctx = nullptr;
+		bool failed_to_create = false;
+		uint64_t frame_number = 0;
+
+		~hip_ray_tracer() noexcept override
+		{
+			rt_hip_destroy(ctx);
+		}
+
+		void render(const rt::scene& scene, image_view& pixels, muu::thread_pool& /*threads*/) noexcept override
+		{
+			if (!pixels || failed_to_create)
+				return;
+
+			if (!ctx && rt_hip_create(&ctx, 0) != RT_HIP_OK)
+			{
+				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+				failed_to_create = true;
+				return;
+			}
+
+			static_assert(sizeof(material_type) == sizeof(uint32_t));
+			static_assert(sizeof(rt::colour) == 4 * sizeof(float));
+
+			rt_hip_scene s{};
+			s.n_spheres				= static_cast<uint32_t>(scene.spheres.size());
+			s.sphere_center_x		= scene.spheres.center_x(); // soagen column accessors, src/soa.hpp
+			s.sphere_center_y		= scene.spheres.center_y();
+			s.sphere_center_z		= scene.spheres.center_z();
+			s.sphere_radius			= scene.spheres.radius();
+			s.sphere_material		= scene.spheres.material();
+			s.n_planes				= static_cast<uint32_t>(scene.planes.size());
+			s.plane_normal_x		= scene.planes.normal_x();
+			s.plane_normal_y		= scene.planes.normal_y();
+			s.plane_normal_z		= scene.planes.normal_z();
+			s.plane_d				= scene.planes.d();
+			s.plane_material		= scene.planes.material();
+			s.n_materials			= static_cast<uint32_t>(scene.materials.size());
+			s.material_type			= reinterpret_cast<const uint32_t*>(scene.materials.type());
+			s.material_albedo		= reinterpret_cast<const float*>(scene.materials.albedo());
+			s.material_roughness	= scene.materials.roughness();
+			s.material_reflectivity = scene.materials.reflectivity();
+			s.samples_per_pixel		= scene.samples_per_pixel;
+			s.max_bounces			= scene.max_bounces;
+
+			// element-wise through m(r, c): independent of muu's storage order (accessor form: src/scene.cpp:179)
+			const auto view = scene.camera.viewport(pixels.size());
+			for (size_t r = 0; r < 4; r++)
+				for (size_t c = 0; c < 4; c++)
+					s.inverse_view_projection[r * 4 + c] = view.inverse_view_projection(r, c);
+
+			// a fresh seed per frame, like the reference's random_device-seeded engines (src/random.cpp:12-13)
+			const char* fixed	= std::getenv("RT_HIP_SEED");
+			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
+
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, RT_HIP_FLAG_NONE, nullptr, nullptr)
+				!= RT_HIP_OK)
+				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+		}
+	};
+
+	REGISTER_RENDERER(hip_ray_tracer);
+}

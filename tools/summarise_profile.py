@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output under gpurun_out/prof into small, committable summaries under profiles/<tag>/.
 
-usage: tools/summarise_profile.py <tag> [note]
+usage: tools/summarise_profile.py <tag> [note] [traffic_key]   (traffic_key e.g. basic_1920x1080x256_n1)
   kernel_stats.csv      <- the --kernel-trace --stats summary (per-kernel count / total / average duration)
   pmc_summary.csv       <- per counter: mean value per render-kernel dispatch, over all --pmc passes found
   pmc_traffic.json (at profiles/) <- HBM bytes per launch from FETCH_SIZE / WRITE_SIZE (guide's gfx950 correction:
@@ -44,4 +44,9 @@ if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         "hbm_bytes_per_launch": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024,
     }
     json.dump(rec, open(out / "hbm_traffic.json", "w"), indent=1)
+    if len(sys.argv) > 3:
+        table_path = root / "profiles" / "pmc_traffic.json"
+        table = json.loads(table_path.read_text()) if table_path.exists() else {}
+        table[sys.argv[3]] = dict(rec, source=f"profiles/{tag}/pmc_summary.csv")
+        json.dump(table, open(table_path, "w"), indent=1, sort_keys=True)
 print(open(out / "pmc_summary.csv").read())
