@@ -34,8 +34,6 @@ namespace rt_hip
 	namespace
 	{
 		constexpr uint32_t block_threads = 256;
-		constexpr uint32_t block_pixels_x = 32;
-		constexpr uint32_t block_pixels_y = 8;
 
 		// best candidate of one linear scan (test_planes / test_spheres, mg_ray_tracer.cpp:36-87)
 		struct candidate
@@ -45,25 +43,45 @@ namespace rt_hip
 			bool have;
 		};
 
-		// One sphere of test_spheres (:70-79) for all lanes at once.  `s` = (center, radius^2), wave-uniform.
-		__device__ __forceinline__ void test_sphere(candidate& best, vec3 o, vec3 d, float4 s, uint32_t index)
+		// One sphere of test_spheres (:70-79) for all lanes at once, in two halves: the part every lane needs
+		// (discriminant) and the part only a possible hit needs (square root, distance, comparison with the best so far).
+		struct sphere_probe
+		{
+			float a, e2, disc;
+			bool pos; // hits_sphere did not return at `if (disc < 0)`
+		};
+
+		__device__ __forceinline__ sphere_probe probe_sphere(vec3 o, vec3 d, float4 s) // s = (center, radius^2), wave-uniform
 		{
 			const vec3 e = { s.x - o.x, s.y - o.y, s.z - o.z };
-			const float a = dot(e, d);
-			const float e2 = dot(e, e);
-			const float disc = s.w - fma(-a, a, e2);
-			const bool pos = !(disc < 0.0f); // hits_sphere: `if (disc < 0) return nullopt`
-			if (__builtin_amdgcn_ballot_w64(pos) != 0) // no lane can hit: skip the square root for the whole wave
+			sphere_probe p;
+			p.a = dot(e, d);
+			p.e2 = dot(e, e);
+			p.disc = s.w - fma(-p.a, p.a, p.e2);
+			p.pos = !(p.disc < 0.0f);
+			return p;
+		}
+
+		// `lanes` = ballot of p.pos
+		__device__ __forceinline__ void finish_sphere(candidate& best, const sphere_probe& p, float r2, uint32_t index, unsigned long long lanes)
+		{
+			if (lanes != 0) // no lane can hit: skip the square root for the whole wave
 			{
-				const float f = sqrt_rn_where(disc, pos); // lanes with disc < 0 never use f
-				const float t = (e2 < s.w) ? a + f : a - f;
+				const float f = sqrt_rn_where(p.disc, p.pos); // lanes with disc < 0 never use f
+				const float t = (p.e2 < r2) ? p.a + f : p.a - f;
 				// hits() holds a value <=> pos && !(t < 0); the scan then drops t < min_hit_dist (which covers
 				// t < 0) and anything not closer than the best so far: `hit_index && hit_dist <= *hit` (:74)
-				const bool accept = pos && !(t < min_hit_dist) && !(best.have && best.t <= t);
+				const bool accept = p.pos && !(t < min_hit_dist) && !(best.have && best.t <= t);
 				best.t = accept ? t : best.t;
 				best.index = accept ? index : best.index;
 				best.have = best.have || accept;
 			}
+		}
+
+		__device__ __forceinline__ void test_sphere(candidate& best, vec3 o, vec3 d, float4 s, uint32_t index)
+		{
+			const sphere_probe p = probe_sphere(o, d, s);
+			finish_sphere(best, p, s.w, index, __builtin_amdgcn_ballot_w64(p.pos));
 		}
 
 		// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
@@ -83,21 +101,40 @@ namespace rt_hip
 			}
 		}
 
-		// scan `count` primitives held in LDS, reading one primitive ahead of the arithmetic
+		// scan `count` primitives held in LDS (wave-uniform addresses: broadcast reads).  Spheres go four at a time:
+		// four independent discriminants (instruction-level parallelism, LDS reads issued together), ONE ballot for
+		// the group; the square-root halves run, in index order, only if some lane may hit one of the four.
 		template <bool SPHERES>
 		__device__ __forceinline__ void scan_lds(candidate& best, vec3 o, vec3 d, const float4* lds, uint32_t count, uint32_t first_index)
 		{
-			if (!count)
-				return;
-			float4 current = lds[0]; // wave-uniform address: broadcast read
-			for (uint32_t i = 0; i < count; i++)
+			uint32_t i = 0;
+			if (SPHERES)
 			{
-				const float4 next = lds[i + 1 < count ? i + 1 : i];
+				for (; i + 4 <= count; i += 4)
+				{
+					const float4 s0 = lds[i], s1 = lds[i + 1], s2 = lds[i + 2], s3 = lds[i + 3];
+					const sphere_probe p0 = probe_sphere(o, d, s0);
+					const sphere_probe p1 = probe_sphere(o, d, s1);
+					const sphere_probe p2 = probe_sphere(o, d, s2);
+					const sphere_probe p3 = probe_sphere(o, d, s3);
+					// the four comparison masks are combined on the scalar unit
+					const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0.pos), m1 = __builtin_amdgcn_ballot_w64(p1.pos);
+					const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2.pos), m3 = __builtin_amdgcn_ballot_w64(p3.pos);
+					if ((m0 | m1 | m2 | m3) != 0)
+					{
+						finish_sphere(best, p0, s0.w, first_index + i, m0);
+						finish_sphere(best, p1, s1.w, first_index + i + 1, m1);
+						finish_sphere(best, p2, s2.w, first_index + i + 2, m2);
+						finish_sphere(best, p3, s3.w, first_index + i + 3, m3);
+					}
+				}
+			}
+			for (; i < count; i++)
+			{
 				if (SPHERES)
-					test_sphere(best, o, d, current, first_index + i);
+					test_sphere(best, o, d, lds[i], first_index + i);
 				else
-					test_plane(best, o, d, current, first_index + i);
-				current = next;
+					test_plane(best, o, d, lds[i], first_index + i);
 			}
 		}
 
@@ -284,7 +321,11 @@ namespace rt_hip
 		// keep waves short, so that a launch has tens of thousands of them to balance over the chip; which lane
 		// computes which chunk cannot change a result.
 		//
-		// NS > 0: `small` kernel, NS spheres in SGPRs (kernel argument).  NS == 0: `resident` kernel, primitives in LDS.
+		// NS > 0: `small` kernel, NS spheres in SGPRs (kernel argument).  NS == 0: `resident` kernel, all primitives in LDS.
+		// NS < 0: `tiled` kernel — the primitives stream from the SoA columns in HBM/L2 through one LDS tile shared by the
+		// workgroup's four waves (coalesced dword per lane per column, radius squared on the way in); every wave still
+		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
+		// each tile, until all four queues are empty.
 		template <int NS>
 		__global__ __launch_bounds__(block_threads) void render_queue(const frame_params p,
 																	  const queue_params q,
@@ -299,7 +340,7 @@ namespace rt_hip
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
 			uint32_t* const lds_metal = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
-			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (s.n_spheres + s.n_planes);
+			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (NS == 0 ? s.n_spheres + s.n_planes : tile_primitives);
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -313,7 +354,7 @@ namespace rt_hip
 					}
 				}
 			}
-			else
+			else if (NS == 0)
 			{
 				for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
 					lds[i] = s.primitive_geometry[i];
@@ -377,11 +418,42 @@ namespace rt_hip
 					}
 					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
 				}
-				if (__builtin_amdgcn_ballot_w64(!retired) == 0)
+				const bool queue_empty = __builtin_amdgcn_ballot_w64(!retired) == 0;
+				if (NS < 0)
+				{
+					if (__syncthreads_and(queue_empty)) // the four waves leave together
+						break;
+				}
+				else if (queue_empty)
 					break;
 
 				// ---- one path segment for every lane that holds an item --------------------------------------------------
-				if (!retired && !want_item)
+				const bool tracing = !retired && !want_item;
+				candidate tiled_planes = { 0.0f, 0u, false };
+				candidate tiled_spheres = { 0.0f, 0u, false };
+				if (NS < 0)
+				{
+					// all 256 threads stage, lanes without an item just do not scan
+					for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
+					{
+						const uint32_t count = min(tile_primitives, s.n_planes - first);
+						__syncthreads(); // previous tile fully consumed
+						stage_planes(lds, s, first, count);
+						__syncthreads();
+						if (tracing)
+							scan_lds<false>(tiled_planes, st.origin, st.dir, lds, count, first);
+					}
+					for (uint32_t first = 0; first < s.n_spheres; first += tile_primitives)
+					{
+						const uint32_t count = min(tile_primitives, s.n_spheres - first);
+						__syncthreads();
+						stage_spheres(lds, s, first, count);
+						__syncthreads();
+						if (tracing)
+							scan_lds<true>(tiled_spheres, st.origin, st.dir, lds, count, first);
+					}
+				}
+				if (tracing)
 				{
 					st.bounces_left--;
 					st.segments++;
@@ -390,7 +462,13 @@ namespace rt_hip
 					vec3 normal = { 0.0f, 0.0f, 0.0f };
 					float4 shading = { 0.0f, 0.0f, 0.0f, 0.0f };
 					bool metal = false;
-					if (NS > 0)
+					if (NS < 0)
+					{
+						uint32_t index;
+						kind = select_hit(tiled_spheres, tiled_planes, distance, index);
+						fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+					}
+					else if (NS > 0)
 					{
 						candidate best = { 0.0f, 0u, false };
 #pragma unroll
@@ -449,102 +527,6 @@ namespace rt_hip
 						colour = colour + vec3{ slots[slot], slots[slot + 1u], slots[slot + 2u] };
 					}
 					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
-				}
-			}
-			add_segments(counters, st.segments);
-		}
-
-		// ---- tiled kernel -----------------------------------------------------------------------------------------
-		// one lane = one pixel, all of its samples in order (the chunk sums are folded as they complete); the
-		// workgroup advances in lock step, one path segment per trip, streaming the primitives through LDS
-		__device__ __forceinline__ bool lane_pixel(const frame_params& p, uint32_t& lx, uint32_t& ly)
-		{
-			const uint32_t lane = threadIdx.x & 63u;
-			const uint32_t wave = threadIdx.x >> 6;
-			lx = blockIdx.x * block_pixels_x + wave * 8u + (lane & 7u);
-			ly = (gridDim.y - 1u - blockIdx.y) * block_pixels_y + (lane >> 3);
-			return lx < p.width && ly < p.local_rows;
-		}
-
-		__global__ __launch_bounds__(block_threads) void render_tiled(const frame_params p,
-																	  const device_scene s,
-																	  uint32_t* __restrict__ out_rgba,
-																	  float* __restrict__ out_rgb,
-																	  device_counters* __restrict__ counters)
-		{
-			__shared__ float4 tile[tile_primitives];
-
-			uint32_t lx, ly;
-			lane_state st;
-			st.segments = 0;
-			vec3 colour = { 0.0f, 0.0f, 0.0f };
-			bool alive = lane_pixel(p, lx, ly);
-			if (alive)
-			{
-				const uint32_t gy = global_row(ly, p);
-				st.fx = static_cast<float>(lx);
-				st.fy = static_cast<float>(gy);
-				st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx);
-				st.chunk_sum = { 0.0f, 0.0f, 0.0f };
-				st.sample = 0;
-				st.sample_end = min(sample_chunk, p.samples_per_pixel);
-				start_sample(st, p);
-			}
-
-			while (__syncthreads_or(alive))
-			{
-				if (alive)
-				{
-					st.bounces_left--;
-					st.segments++;
-				}
-				candidate planes = { 0.0f, 0u, false };
-				candidate spheres = { 0.0f, 0u, false };
-				for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
-				{
-					const uint32_t count = min(tile_primitives, s.n_planes - first);
-					__syncthreads(); // previous tile fully consumed
-					stage_planes(tile, s, first, count);
-					__syncthreads();
-					if (alive)
-						scan_lds<false>(planes, st.origin, st.dir, tile, count, first);
-				}
-				for (uint32_t first = 0; first < s.n_spheres; first += tile_primitives)
-				{
-					const uint32_t count = min(tile_primitives, s.n_spheres - first);
-					__syncthreads();
-					stage_spheres(tile, s, first, count);
-					__syncthreads();
-					if (alive)
-						scan_lds<true>(spheres, st.origin, st.dir, tile, count, first);
-				}
-				if (alive)
-				{
-					float distance;
-					uint32_t index;
-					const uint32_t kind = select_hit(spheres, planes, distance, index);
-					vec3 normal;
-					float4 shading;
-					bool metal;
-					fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
-					vec3 contribution;
-					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
-					{
-						st.chunk_sum = st.chunk_sum + contribution;
-						if (++st.sample >= st.sample_end) // chunk complete: fold it (the first chunk IS the running total)
-						{
-							colour = st.sample <= sample_chunk ? st.chunk_sum : colour + st.chunk_sum;
-							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
-							st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
-						}
-						if (st.sample >= p.samples_per_pixel)
-						{
-							alive = false;
-							finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
-						}
-						else
-							start_sample(st, p);
-					}
 				}
 			}
 			add_segments(counters, st.segments);
@@ -735,12 +717,6 @@ namespace rt_hip
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
-		if (variant == RT_HIP_KERNEL_TILED)
-		{
-			const dim3 grid((frame.width + block_pixels_x - 1) / block_pixels_x, (frame.local_rows + block_pixels_y - 1) / block_pixels_y);
-			hipLaunchKernelGGL(render_tiled, grid, dim3(block_threads), 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
-			return variant;
-		}
 		const queue_params queue = choose_queue(frame.samples_per_pixel);
 		const uint32_t tile_w = 1u << queue.tile_w_log2;
 		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
@@ -762,8 +738,13 @@ namespace rt_hip
 			}
 			return variant;
 		}
-		const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
-		launch_queue<0>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+		if (variant == RT_HIP_KERNEL_RESIDENT)
+		{
+			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
+			launch_queue<0>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			return variant;
+		}
+		launch_queue<-1>(frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 		return variant;
 	}
 
