@@ -181,7 +181,7 @@ def main() -> None:
             },
         }
         line = {
-            "metric": "Mrays/s (W*H*spp per second) and wall-clock, 1920x1080x256spp scenes/basic.toml",
+            "metric": f"Mrays/s (W*H*spp per second) and wall-clock, {args.width}x{args.height}x{args.spp}spp scenes/{args.scene}.toml",
             "value": round(value, 1),
             "unit": "Mrays/s",
             "n_gpus": world,

@@ -692,13 +692,17 @@ namespace rt_hip
 		return RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels)
 	{
-		// K chunks per pixel; P pixels per wave so that a wave's queue holds about 256 items (4 per lane)
+		// K chunks per pixel; P pixels per wave.  A queue of about 256 items (4 per lane) keeps the lanes of a wave
+		// evenly busy; a launch also wants several tens of thousands of waves to balance over 1024 SIMDs, so smaller
+		// frames get queues of 128 items (measured on 1920x1080 and 960x540 at 64 and 256 spp: profiles/r01/queue_shape_sweep.txt).
 		queue_params q{};
 		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk;
 		uint32_t pixels_log2 = 6; // 64 pixels = 8 x 8
 		while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
+			pixels_log2--;
+		if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
 			pixels_log2--;
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 8x8, 8x4, 4x4, 4x2, 2x2
@@ -717,7 +721,7 @@ namespace rt_hip
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
-		const queue_params queue = choose_queue(frame.samples_per_pixel);
+		const queue_params queue = choose_queue(frame.samples_per_pixel, static_cast<uint64_t>(frame.width) * frame.local_rows);
 		const uint32_t tile_w = 1u << queue.tile_w_log2;
 		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
 		const dim3 grid((frame.width + 4u * tile_w - 1u) / (4u * tile_w), (frame.local_rows + tile_h - 1u) / tile_h);
