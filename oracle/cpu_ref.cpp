@@ -86,8 +86,9 @@ namespace
 	//   hash32  = the "lowbias32" integer finaliser (xorshift-multiply, two rounds)
 	//   frame   = hash32(lo32(seed) ^ hash32(hi32(seed) ^ 0x9E3779B9))
 	//   pixel   = hash32(frame ^ pixel_index)
-	//   counter = hash32(pixel + sample_index)
+	//   counter = pixel + sample_index * (0x9E3779B9 * 4096)            (mod 2^32; 4096 draws reserved per sample)
 	//   draw    : counter += 0x9E3779B9;  u = float(hash32(counter) >> 8) * 2^-24      in [0, 1)
+	// i.e. all draws of a pixel are hash32 of one arithmetic progression (a Weyl sequence) starting at a hashed offset.
 	inline uint32_t hash32(uint32_t x)
 	{
 		x ^= x >> 16;
@@ -108,7 +109,7 @@ namespace
 		uint32_t counter;
 
 		random_stream(uint32_t frame, uint32_t pixel_index, uint32_t sample_index)
-			: counter{ hash32(hash32(frame ^ pixel_index) + sample_index) }
+			: counter{ hash32(frame ^ pixel_index) + sample_index * (0x9E3779B9u * 4096u) }
 		{}
 
 		// random<float>(), src/random.hpp:12-17 / src/random.cpp:20-26: uniform in [0, 1)

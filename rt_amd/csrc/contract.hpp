@@ -72,8 +72,9 @@ namespace rt_hip
 		return q;
 	}
 
-	// The general expansions sit behind a wave-uniform branch that is practically never taken.  The empty asm
-	// statement keeps hipcc from if-converting that branch (it would otherwise evaluate both sides on every call).
+	// The general expansions sit behind a branch that is practically never taken (hipcc skips it with one
+	// s_cbranch_execz).  The empty asm statement keeps hipcc from if-converting that branch (it would otherwise
+	// evaluate both sides on every call).
 #define RT_HIP_RARE_PATH() asm volatile("; rare path: general IEEE expansion" ::: "memory")
 
 	// == __builtin_sqrtf(x) in every lane where `wanted` holds (other lanes get an unspecified finite value)
@@ -82,12 +83,10 @@ namespace rt_hip
 		const bool fast = in_fast_band(x);
 		float h;
 		float s = sqrt_core(fast ? x : 1.0f, h);
-		const bool general = wanted && !fast; // 0, subnormal, huge, infinite, negative or NaN
-		if (__builtin_amdgcn_ballot_w64(general) != 0)
+		if (wanted && !fast) // 0, subnormal, huge, infinite, negative or NaN
 		{
 			RT_HIP_RARE_PATH();
-			const float g = __builtin_sqrtf(x);
-			s = general ? g : s;
+			s = __builtin_sqrtf(x);
 		}
 		return s;
 	}
@@ -101,11 +100,10 @@ namespace rt_hip
 		const bool fast = in_fast_band(__builtin_fabsf(x));
 		const float xs = fast ? x : 1.0f;
 		float q = rcp_core(xs, __builtin_amdgcn_rcpf(xs));
-		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		if (!fast)
 		{
 			RT_HIP_RARE_PATH();
-			const float g = 1.0f / x;
-			q = fast ? q : g;
+			q = 1.0f / x;
 		}
 		return q;
 	}
@@ -120,11 +118,10 @@ namespace rt_hip
 		float h;
 		const float s = sqrt_core(fast ? x : 1.0f, h); // in [2^-30, 2^30): inside the reciprocal's band as well
 		float q = rcp_core(s, __builtin_amdgcn_rcpf(s));
-		if (__builtin_amdgcn_ballot_w64(!fast) != 0)
+		if (!fast)
 		{
 			RT_HIP_RARE_PATH();
-			const float g = 1.0f / __builtin_sqrtf(x);
-			q = fast ? q : g;
+			q = 1.0f / __builtin_sqrtf(x);
 		}
 		return q;
 	}
@@ -156,12 +153,15 @@ namespace rt_hip
 	}
 
 	__device__ __forceinline__ uint32_t pixel_key(uint32_t frame, uint32_t pixel_index) { return hash32(frame ^ pixel_index); }
-	__device__ __forceinline__ uint32_t sample_counter(uint32_t pixel, uint32_t sample_index) { return hash32(pixel + sample_index); }
+	// stream position before the first draw of sample `sample_index`: 4096 draws are reserved per sample
+	constexpr uint32_t draw_stride = 0x9E3779B9u;
+	constexpr uint32_t sample_stride = draw_stride * 4096u; // mod 2^32
+	__device__ __forceinline__ uint32_t sample_counter(uint32_t pixel, uint32_t sample_index) { return pixel + sample_index * sample_stride; }
 
 	// random<float>(), src/random.hpp:12-17: uniform in [0, 1)
 	__device__ __forceinline__ float next_random(uint32_t& counter)
 	{
-		counter += 0x9E3779B9u;
+		counter += draw_stride;
 		return static_cast<float>(hash32(counter) >> 8) * 0x1.0p-24f;
 	}
 

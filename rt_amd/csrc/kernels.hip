@@ -186,81 +186,6 @@ namespace rt_hip
 			uint32_t segments;
 		};
 
-		// worker lambda :189-193 — jittered position, un-project to near and far, build the primary ray
-		__device__ __forceinline__ void start_sample(lane_state& st, const frame_params& p)
-		{
-			st.counter = sample_counter(st.pixel_key, st.sample);
-			float jx = 0.5f, jy = 0.5f; // sample 0: pixel centre
-			if (st.sample)
-			{
-				jx = next_random(st.counter);
-				jy = next_random(st.counter);
-			}
-			const float px = st.fx + jx;
-			const float py = st.fy + jy;
-			const float ndc_x = fma(px, p.sx, -1.0f);
-			const float ndc_y = fma(py, p.neg_sy, 1.0f);
-			float near_row[3], far_row[3];
-#pragma unroll
-			for (int r = 0; r < 3; r++)
-			{
-				near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
-				far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
-			}
-			float inv_wn = p.inv_w_near, inv_wf = p.inv_w_far;
-			if (!p.uniform_w) // wave-uniform (kernel argument)
-			{
-				inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
-				inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
-			}
-			const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
-			const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
-			st.origin = near_pos;
-			st.dir = normalize(far_pos - near_pos);
-			st.throughput = { 1.0f, 1.0f, 1.0f };
-			st.bounces_left = p.max_bounces;
-		}
-
-		// The part of trace() after the closest-hit query (:163-173) for one segment.
-		// kind 0 = miss; otherwise `normal` is the hit normal, `shading` = (attenuation.rgb, roughness), `metal` the
-		// scatter function (:142-152).  Returns true when the path ended; `contribution` is then the sample's value.
-		__device__ __forceinline__ bool
-		shade_segment(lane_state& st, uint32_t kind, float distance, vec3 normal, float4 shading, bool metal, vec3& contribution)
-		{
-			if (!kind)
-			{
-				contribution = st.throughput * sky(st.dir.y); // :163-164
-				return true;
-			}
-			const vec3 hit_pos = ray_at(st.origin, st.dir, distance);
-			vec3 base = normal;
-			float spread = 1.0f;
-			if (metal)
-			{
-				// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
-				const vec3 v = normalize(st.dir);
-				const float k = 2.0f * dot(v, normal);
-				base = { fma(-k, normal.x, v.x), fma(-k, normal.y, v.y), fma(-k, normal.z, v.z) };
-				spread = shading.w;
-			}
-			const vec3 u = random_unit_vector(st.counter);
-			// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
-			vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
-			bool absorbed = false;
-			if (metal)
-				absorbed = dot(scatter, normal) <= 0.0f; // (:135-136)
-			else if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon
-					 && __builtin_fabsf(scatter.z) <= approx_zero_epsilon)
-				scatter = normal; // (:118-119)
-
-			st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
-			st.origin = hit_pos;
-			st.dir = normalize(scatter);
-			// absorbed, or the next trace() call would return {} at :157-158
-			contribution = { 0.0f, 0.0f, 0.0f };
-			return absorbed || st.bounces_left == 0;
-		}
-
 		__device__ __forceinline__ uint32_t global_row(uint32_t local_row, const frame_params& p)
 		{
 			return ((local_row / p.stripe_rows) * p.world + p.rank) * p.stripe_rows + (local_row % p.stripe_rows);
@@ -295,10 +220,8 @@ namespace rt_hip
 		__device__ __forceinline__ void
 		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, bool& metal)
 		{
-			normal = { 0.0f, 0.0f, 0.0f };
-			shading = { 0.0f, 0.0f, 0.0f, 0.0f };
 			metal = false;
-			if (kind)
+			if (kind) // normal and shading are meaningful only for a hit
 			{
 				const uint32_t primitive = kind == 1u ? index : s.n_spheres + index;
 				const float4 g = s.primitive_geometry[primitive];
@@ -375,26 +298,41 @@ namespace rt_hip
 
 			lane_state st;
 			st.segments = 0;
-			uint32_t next_item = 0;	 // wave-uniform queue head
-			uint32_t item = 0;		 // item in flight on this lane
-			bool want_item = true;	 // lane is free
-			bool retired = false;	 // queue ran dry for this lane
+			uint32_t next_item = 0; // wave-uniform queue head
+			uint32_t item = 0;		// item in flight on this lane
+			// what the lane does in the current trip:
+			//   free    - between items                       restart - has a sample to start (needs a primary ray)
+			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
+			enum : uint32_t { lane_free, lane_restart, lane_trace, lane_retired };
+			uint32_t mode = lane_free;
+
+			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
+			const auto end_sample = [&](vec3 contribution)
+			{
+				st.chunk_sum = st.chunk_sum + contribution;
+				if (++st.sample < st.sample_end)
+					mode = lane_restart;
+				else
+				{
+					slots[item * 3u + 0u] = st.chunk_sum.x;
+					slots[item * 3u + 1u] = st.chunk_sum.y;
+					slots[item * 3u + 2u] = st.chunk_sum.z;
+					mode = lane_free;
+				}
+			};
 
 			while (true)
 			{
 				// ---- hand out items to free lanes (converged) ---------------------------------------------------------
-				const unsigned long long asking = __builtin_amdgcn_ballot_w64(want_item);
+				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
 				if (asking != 0)
 				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
-					if (want_item)
+					if (mode == lane_free)
 					{
 						item = next_item + rank;
 						if (item >= items)
-						{
-							retired = true;
-							want_item = false;
-						}
+							mode = lane_retired;
 						else
 						{
 							const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
@@ -410,15 +348,14 @@ namespace rt_hip
 								st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 								st.sample = chunk * sample_chunk;
 								st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
-								start_sample(st, p);
-								want_item = false;
+								mode = lane_restart;
 							}
 							// else: a pixel outside the frame — the item is empty, ask again next trip
 						}
 					}
 					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
 				}
-				const bool queue_empty = __builtin_amdgcn_ballot_w64(!retired) == 0;
+				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
 				if (NS < 0)
 				{
 					if (__syncthreads_and(queue_empty)) // the four waves leave together
@@ -427,13 +364,13 @@ namespace rt_hip
 				else if (queue_empty)
 					break;
 
-				// ---- one path segment for every lane that holds an item --------------------------------------------------
-				const bool tracing = !retired && !want_item;
+				// ---- closest-hit query for every lane that holds a ray (trace(), :160-162) -----------------------------------
+				const bool tracing = mode == lane_trace;
 				candidate tiled_planes = { 0.0f, 0u, false };
 				candidate tiled_spheres = { 0.0f, 0u, false };
 				if (NS < 0)
 				{
-					// all 256 threads stage, lanes without an item just do not scan
+					// all 256 threads stage, lanes without a ray just do not scan
 					for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
 					{
 						const uint32_t count = min(tile_primitives, s.n_planes - first);
@@ -453,15 +390,22 @@ namespace rt_hip
 							scan_lds<true>(tiled_spheres, st.origin, st.dir, lds, count, first);
 					}
 				}
+
+				// After the query a lane either SHADES a hit (scatter: three draws, a new direction) or, having missed,
+				// RESTARTS with the next sample's primary ray (two draws, a new direction).  Both end in the same
+				// operations — random draws and the normalisation of a direction — which are therefore issued once for
+				// the whole wave; only the pieces that really differ run under their own lane masks.
+				bool shade = false;
+				vec3 normal, base, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
+				float4 shading;
+				float spread = 1.0f;
+				bool metal = false;
 				if (tracing)
 				{
-					st.bounces_left--;
+					st.bounces_left--; // `if (!(max_bounces--)) return {}` (:157) is checked when the bounce is made, below
 					st.segments++;
 					uint32_t kind;
 					float distance;
-					vec3 normal = { 0.0f, 0.0f, 0.0f };
-					float4 shading = { 0.0f, 0.0f, 0.0f, 0.0f };
-					bool metal = false;
 					if (NS < 0)
 					{
 						uint32_t index;
@@ -495,20 +439,99 @@ namespace rt_hip
 						kind = select_hit(spheres, planes, distance, index);
 						fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
 					}
-					vec3 contribution;
-					if (shade_segment(st, kind, distance, normal, shading, metal, contribution))
+					if (!kind)
+						end_sample(st.throughput * sky(st.dir.y)); // miss (:163-164)
+					else
 					{
-						st.chunk_sum = st.chunk_sum + contribution;
-						if (++st.sample < st.sample_end)
-							start_sample(st, p);
-						else
+						shade = true;
+						hit_pos = ray_at(st.origin, st.dir, distance);
+						base = normal;
+						if (metal)
 						{
-							slots[item * 3u + 0u] = st.chunk_sum.x;
-							slots[item * 3u + 1u] = st.chunk_sum.y;
-							slots[item * 3u + 2u] = st.chunk_sum.z;
-							want_item = true;
+							// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
+							const vec3 v = normalize(st.dir);
+							const float k = 2.0f * dot(v, normal);
+							base = { fma(-k, normal.x, v.x), fma(-k, normal.y, v.y), fma(-k, normal.z, v.z) };
+							spread = shading.w;
 						}
 					}
+				}
+
+				const bool restart = mode == lane_restart;
+				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
+				{
+					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
+					uint32_t counter = restart ? sample_counter(st.pixel_key, st.sample) : st.counter;
+					const uint32_t counter_at_start = counter;
+					float d0 = next_random(counter);
+					float d1 = next_random(counter);
+					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
+					bool absorbed = false;
+					if (shade)
+					{
+						float d2 = next_random(counter);
+						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
+						{
+							d0 = next_random(counter);
+							d1 = next_random(counter);
+							d2 = next_random(counter);
+						}
+						const vec3 u = normalize({ d0, d1, d2 });
+						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
+						vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
+						if (metal)
+							absorbed = dot(scatter, normal) <= 0.0f; // (:135-136)
+						else if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon
+								 && __builtin_fabsf(scatter.z) <= approx_zero_epsilon)
+							scatter = normal; // (:118-119)
+						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z }; // attenuation * trace(...) (:171)
+						st.origin = hit_pos;
+						toward = scatter;
+					}
+					else if (restart)
+					{
+						// worker lambda :189-193 — jittered position, un-project to near and far, build the primary ray
+						float jx = 0.5f, jy = 0.5f; // sample 0 goes through the pixel centre and draws nothing
+						if (st.sample)
+						{
+							jx = d0;
+							jy = d1;
+						}
+						else
+							counter = counter_at_start;
+						const float px = st.fx + jx;
+						const float py = st.fy + jy;
+						const float ndc_x = fma(px, p.sx, -1.0f);
+						const float ndc_y = fma(py, p.neg_sy, 1.0f);
+						float near_row[3], far_row[3];
+#pragma unroll
+						for (int r = 0; r < 3; r++)
+						{
+							near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
+							far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
+						}
+						float inv_wn = p.inv_w_near, inv_wf = p.inv_w_far;
+						if (!p.uniform_w) // wave-uniform (kernel argument)
+						{
+							inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
+							inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
+						}
+						const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
+						const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
+						st.origin = near_pos;
+						toward = far_pos - near_pos; // vec3::direction(near, far) (:193)
+						st.throughput = { 1.0f, 1.0f, 1.0f };
+						st.bounces_left = p.max_bounces;
+						mode = lane_trace;
+					}
+					if (shade || restart)
+					{
+						st.counter = counter;
+						st.dir = normalize(toward);
+					}
+					// absorbed, or the next trace() call would return {} at :157-158: the sample is worth nothing
+					if (shade && (absorbed || st.bounces_left == 0))
+						end_sample({ 0.0f, 0.0f, 0.0f });
 				}
 			}
 
@@ -608,6 +631,8 @@ namespace rt_hip
 				float4 shading;
 				bool metal;
 				fetch_hit(s, o, d, kind, distance, index, normal, shading, metal);
+				if (!kind)
+					normal = { 0.0f, 0.0f, 0.0f }; // hit_result{ -1 } of the reference: no normal
 				out_distance[i] = distance;
 				out_kind[i] = kind;
 				out_index[i] = kind ? index : 0u;
