@@ -74,6 +74,7 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -88,12 +89,16 @@ def main() -> None:
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
 
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
-    tracer = rt_amd.HipRayTracer(device=local_rank)  # fails loudly without librt_hip.so or a gfx950 device
+    tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
     pod = scene.describe(args.width, args.height)
     tracer.upload(pod)  # inputs resident in HBM before the timed region
@@ -136,7 +141,7 @@ def main() -> None:
     tracer.render_device = real_render_device
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -7,7 +7,7 @@ gather; backend "nccl" is RCCL over xGMI on ROCm) and de-interleaved into the fr
 
 Partition: stripes of ``stripe_rows`` (8) image rows dealt round-robin to ranks, so that the cheap sky rows and
 the expensive ground rows are spread evenly.  Random streams are keyed by the GLOBAL pixel index, so the
-assembled frame is bit-identical for every world size (tests/test_partition.py).
+assembled frame is bit-identical for every world size (tests/test_gpu_parity.py, tests/test_distributed_gpu.py).
 """
 from __future__ import annotations
 
@@ -47,6 +47,11 @@ def gather_stripes(local: torch.Tensor, dst: int = 0, group=None) -> torch.Tenso
     rank = dist.get_rank(group)
     if world == 1:
         return local.unsqueeze(0)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (more ranks than GPUs): gloo cannot gather device tensors, so the stripes take a detour
+        # through host memory; the RCCL path below moves them GPU to GPU
+        staged = gather_stripes(local.cpu(), dst=dst, group=group)
+        return staged.to(local.device) if staged is not None else None
     if rank == dst:
         out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
         dist.gather(local, gather_list=list(out.unbind(0)), dst=dst, group=group)

@@ -1,0 +1,61 @@
+"""bench.py keeps the driver's contract: flags, ONE JSON line, the keys and objects the judge reads."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import ROOT
+
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"}
+
+
+def test_algorithmic_flops_formula():
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    # S*70 + segments*(22*N_s + 16*N_p + 60)
+    assert bench.algorithmic_flops(10, 16, 3, 0) == 10 * 70 + 16 * (66 + 60)
+    assert bench.algorithmic_flops(1, 1, 100000, 2) == 70 + (2200000 + 32 + 60)
+
+
+def run_bench(args, launcher=None, timeout=600):
+    cmd = (launcher or [sys.executable]) + [str(ROOT / "bench.py")] + args
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_single_gpu_line_has_the_contract_keys_roofline_and_cpu_baseline():
+    line = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--spp", "32", "--cpu-baseline-seconds", "1"])
+    assert REQUIRED <= set(line)
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 1
+    assert line["unit"] == "Mrays/s" and line["higher_is_better"] is True and line["scaling"] == "strong" and line["vs_baseline"] is None
+    assert line["dtype"] == "f32" and "workload" in line["config"] and "model" not in line["config"]
+    assert line["value"] == pytest.approx(1920 * 1080 * 32 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    roof = line["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(roof)
+    assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3) and 0 < roof["frac"] < 1
+    cpu = line["cpu_baseline"]
+    assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] >= 1
+    assert line["drop_in_render"]["wall_ms"] > 0
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_step():
+    """The N>1 flow of bench.py — per-rank stripes, gather to rank 0, device assemble, max-over-ranks timing — with
+    both ranks sharing the single GPU of this box and gloo as the transport (RCCL refuses two ranks on one device)."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
+    assert line["n_gpus"] == 2 and "cpu_baseline" not in line
+    assert "RCCL gather" in line["config"]["parallelism"]
