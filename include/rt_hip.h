@@ -145,7 +145,12 @@ enum
 	/* force the LDS-tiled kernel even for scenes that fit a smaller one (testing) */
 	RT_HIP_FLAG_FORCE_TILED = 1u << 0,
 	/* force the LDS-resident kernel for scenes that would take the scalar-register one (testing) */
-	RT_HIP_FLAG_FORCE_RESIDENT = 1u << 1
+	RT_HIP_FLAG_FORCE_RESIDENT = 1u << 1,
+	/* rt_hip_render only: the caller promises that `pixels_rgba8888` stays allocated, at this address and size, until
+	 * the next rt_hip_render call on this context or rt_hip_destroy — as rt's back buffer does (one image per window
+	 * size, reference src/window.cpp:61-64, src/back_buffer.cpp).  The module then page-locks the buffer once and the
+	 * per-frame read-back becomes a single DMA.  Without the flag the buffer is treated as ordinary pageable memory. */
+	RT_HIP_FLAG_PERSISTENT_FRAME = 1u << 2
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

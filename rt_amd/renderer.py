@@ -61,9 +61,12 @@ class HipRayTracer:
         self.close()
 
     # ---- drop-in ------------------------------------------------------------------------------------------
-    def render(self, scene: RtHipScene, width: int, height: int, seed: int = 1, flags: int = 0, want_rgb: bool = False):
-        """rt_hip_render: returns (rgba8 uint32[H, W], rgb float32[H, W, 3] or None, stats dict)."""
-        rgba = np.empty((height, width), dtype=np.uint32)
+    def render(self, scene: RtHipScene, width: int, height: int, seed: int = 1, flags: int = 0, want_rgb: bool = False, out: np.ndarray | None = None):
+        """rt_hip_render: returns (rgba8 uint32[H, W], rgb float32[H, W, 3] or None, stats dict).
+
+        `out`: a uint32[H, W] array to render into (like rt's persistent back buffer); a fresh one otherwise."""
+        rgba = out if out is not None else np.empty((height, width), dtype=np.uint32)
+        assert rgba.dtype == np.uint32 and rgba.shape == (height, width) and rgba.flags.c_contiguous
         rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
         stats = RtHipStats()
         check(

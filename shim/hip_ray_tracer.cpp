@@ -81,7 +81,7 @@ namespace
 			const char* fixed	= std::getenv("RT_HIP_SEED");
 			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
 
-			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, RT_HIP_FLAG_NONE, nullptr, nullptr)
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, RT_HIP_FLAG_PERSISTENT_FRAME, nullptr, nullptr)
 				!= RT_HIP_OK)
 				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
 		}

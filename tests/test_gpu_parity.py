@@ -187,6 +187,36 @@ def test_empty_scene_renders_sky(tracer):
         assert stats["segments"] == 40 * 24 * 3
 
 
+def test_persistent_back_buffer_and_unchanged_scene_take_the_fast_path_and_stay_correct(tracer):
+    """rt renders into one back buffer frame after frame and usually with an unchanged scene: the module page-locks
+    that buffer and skips the re-upload; a changed scene or a new buffer must still give the right frame."""
+    width, height = 120, 68
+    back = np.zeros((height, width), dtype=np.uint32)
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    pod = scene.describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=3, want_rgb=False)
+    PERSISTENT = capi.RT_HIP_FLAG_PERSISTENT_FRAME
+    for _ in range(3):
+        back[:] = 0
+        tracer.render(pod, width, height, seed=3, out=back, flags=PERSISTENT)
+        assert np.array_equal(back, want)
+    # same buffer, different scene content (same sizes): the fingerprint must notice
+    scene2 = rt_amd.Scene.named("basic").set_sampling(4).set_camera((0.5, 1.2, 3.0), (0.0, -0.1, -1.0))
+    pod2 = scene2.describe(width, height)
+    want2, _, _ = oracle.render(pod2, width, height, seed=3, want_rgb=False)
+    tracer.render(pod2, width, height, seed=3, out=back, flags=PERSISTENT)
+    assert np.array_equal(back, want2) and not np.array_equal(want, want2)
+    # a new buffer of another size
+    other = np.zeros((height // 2, width), dtype=np.uint32)
+    pod3 = scene.describe(width, height // 2)
+    tracer.render(pod3, width, height // 2, seed=3, out=other, flags=PERSISTENT)
+    want3, _, _ = oracle.render(pod3, width, height // 2, seed=3, want_rgb=False)
+    assert np.array_equal(other, want3)
+    # and a call without the flag releases the registration again
+    tracer.render(pod3, width, height // 2, seed=3, out=other)
+    assert np.array_equal(other, want3)
+
+
 def test_seed_changes_the_image_and_equal_seeds_repeat_it(tracer):
     scene = rt_amd.Scene.named("basic").set_sampling(4)
     pod = scene.describe(96, 54)
