@@ -150,7 +150,12 @@ enum
 	 * the next rt_hip_render call on this context or rt_hip_destroy — as rt's back buffer does (one image per window
 	 * size, reference src/window.cpp:61-64, src/back_buffer.cpp).  The module then page-locks the buffer once and the
 	 * per-frame read-back becomes a single DMA.  Without the flag the buffer is treated as ordinary pageable memory. */
-	RT_HIP_FLAG_PERSISTENT_FRAME = 1u << 2
+	RT_HIP_FLAG_PERSISTENT_FRAME = 1u << 2,
+	/* shade with sm_ray_tracer's scatter table (reference src/renderers/sm_ray_tracer.cpp:221-236) instead of
+	 * mg_ray_tracer's: dielectric, air, vacuum, water and ice refract/reflect through dielectric_scatter (:181-219),
+	 * with the material's reflectivity as index of refraction.  Everything else is unchanged.  Opt-in: the parity
+	 * contract of this module is mg_ray_tracer, under which those materials are lambert. */
+	RT_HIP_FLAG_SM_MATERIALS = 1u << 3
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

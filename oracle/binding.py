@@ -16,6 +16,7 @@ from rt_amd.capi import RtHipPartition, RtHipScene
 ORACLE_DIR = Path(__file__).resolve().parent
 TRACE_ITERATIVE = 0
 TRACE_RECURSIVE = 1
+MATERIALS_SM = 2
 
 
 class OracleStats(C.Structure):
@@ -62,6 +63,8 @@ def lib() -> C.CDLL:
         l.oracle_sky.argtypes = [C.c_float, C.c_void_p]
         l.oracle_primary_ray.restype = None
         l.oracle_primary_ray.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        l.oracle_dielectric_direction.restype = None
+        l.oracle_dielectric_direction.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib = l
     return _lib
 
@@ -70,14 +73,14 @@ def _local_rows(height, rank, world, stripe):
     return sum(1 for y in range(height) if (y // stripe) % world == rank)
 
 
-def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_order: int = TRACE_ITERATIVE, partition=None, want_rgb=True, threads: int = 0):
+def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_order: int = TRACE_ITERATIVE, partition=None, want_rgb=True, threads: int = 0, sm_materials: bool = False):
     """Counter-RNG strict-IEEE render.  Returns (rgba uint32[rows, W], rgb float32[rows, W, 3] | None, stats dict)."""
     rows = height if partition is None else _local_rows(height, *partition)
     rgba = np.zeros((rows, width), dtype=np.uint32)
     rgb = np.zeros((rows, width, 3), dtype=np.float32) if want_rgb else None
     stats = OracleStats()
     part = C.byref(RtHipPartition(*partition)) if partition is not None else None
-    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order, part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order | (MATERIALS_SM if sm_materials else 0), part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed ({rc})")
     return rgba, rgb, stats.as_dict()
@@ -135,3 +138,13 @@ def primary_ray(scene: RtHipScene, width: int, height: int, px: float, py: float
     d = np.empty(3, dtype=np.float32)
     lib().oracle_primary_ray(C.byref(scene), width, height, px, py, o.ctypes.data, d.ctypes.data)
     return o, d
+
+
+def dielectric_direction(direction, normal, reflectivity: float, u: float):
+    """(new direction, reflect probability) of sm_ray_tracer's dielectric_scatter for the uniform number u."""
+    d = np.ascontiguousarray(direction, dtype=np.float32)
+    n = np.ascontiguousarray(normal, dtype=np.float32)
+    out = np.empty(3, dtype=np.float32)
+    prob = C.c_float()
+    lib().oracle_dielectric_direction(d.ctypes.data, n.ctypes.data, reflectivity, u, out.ctypes.data, C.byref(prob))
+    return out, prob.value

@@ -141,6 +141,7 @@ namespace
 		uint32_t type;
 		vec3 attenuation; // vec3{ albedo * reflectivity }, mg_ray_tracer.cpp:115,131 (colour * float, colour.hpp:144-149)
 		float roughness;
+		float reflectivity; // doubles as the index of refraction in sm_ray_tracer's dielectric_scatter
 	};
 
 	struct frame
@@ -151,9 +152,10 @@ namespace
 		float sx, sy; // 2 / W, 2 / H
 		uint32_t frame_key;
 		int trace_order;
+		bool sm_materials;
 	};
 
-	inline frame make_frame(const rt_hip_scene* s, uint32_t w, uint32_t h, uint64_t seed, int trace_order)
+	inline frame make_frame(const rt_hip_scene* s, uint32_t w, uint32_t h, uint64_t seed, int mode)
 	{
 		frame f{};
 		f.scene = s;
@@ -162,7 +164,8 @@ namespace
 		f.sx = 2.0f / static_cast<float>(w);
 		f.sy = 2.0f / static_cast<float>(h);
 		f.frame_key = frame_key(seed);
-		f.trace_order = trace_order;
+		f.trace_order = mode & ORACLE_TRACE_RECURSIVE;
+		f.sm_materials = (mode & ORACLE_MATERIALS_SM) != 0;
 		f.materials.resize(s->n_materials);
 		for (uint32_t m = 0; m < s->n_materials; m++)
 		{
@@ -172,6 +175,7 @@ namespace
 										   s->material_albedo[m * 4 + 1] * refl,
 										   s->material_albedo[m * 4 + 2] * refl };
 			f.materials[m].roughness = s->material_roughness[m];
+			f.materials[m].reflectivity = refl;
 		}
 		return f;
 	}
@@ -349,13 +353,79 @@ namespace
 		return true;
 	}
 
+	// sm_ray_tracer.cpp:181-219 (with refract :161-172 and schlick :174-179), opt-in.
+	// `refl` = the material's reflectivity column, used by the reference as the index of refraction.
+	// Contract details: sin2_t = (eta*eta) * fma(-cos_i, cos_i, 1); cos_t = sqrtf(1 - sin2_t);
+	// refracted = fma(k, n, eta*v) with k = fma(eta, cos_i, -cos_t); schlick's fifth power is taken in double by
+	// three multiplications ((x*x)*(x*x))*x of x = (double)(1.0f - cosine) — the reference calls pow(double, int) —
+	// and r0 + (1 - r0) * x^5 is evaluated in double with (1 - r0) in float, as the reference's promotions do.
+	// The new direction is NOT normalised (the reference returns `reflected` / `refracted` as they are).
+	inline vec3 dielectric_direction(vec3 d, vec3 n, float refl, float u, float* out_reflect_prob = nullptr);
+
+	inline bool dielectric_scatter(const ray& r, const hit_result& hit, float refl, random_stream& rng, ray& out)
+	{
+		// argument evaluation order does not matter: exactly one draw
+		out = { r.at(hit.distance), dielectric_direction(r.dir, hit.normal, refl, rng.next()) };
+		return true;
+	}
+
+	inline vec3 dielectric_direction(vec3 d, vec3 n, float refl, float u, float* out_reflect_prob)
+	{
+		const float dn = dot(d, n);
+		const float k = 2.0f * dn;
+		const vec3 reflected = { std::fmaf(-k, n.x, d.x), std::fmaf(-k, n.y, d.y), std::fmaf(-k, n.z, d.z) };
+		const float len = std::sqrt(dot(d, d));
+		vec3 outward;
+		float eta, cosine;
+		if (dn > 0.0f)
+		{
+			outward = { -n.x, -n.y, -n.z };
+			eta = refl;
+			cosine = (refl * dn) / len;
+		}
+		else
+		{
+			outward = n;
+			eta = 1.0f / refl;
+			cosine = (-dn) / len;
+		}
+		float reflect_prob = 1.0f;
+		vec3 refracted = { 0, 0, 0 };
+		const float cos_i = -dot(d, outward);
+		const float sin2_t = (eta * eta) * std::fmaf(-cos_i, cos_i, 1.0f);
+		if (!(sin2_t > 1.0f)) // refract() returned true
+		{
+			const float cos_t = std::sqrt(1.0f - sin2_t);
+			const float kk = std::fmaf(eta, cos_i, -cos_t);
+			refracted = { std::fmaf(kk, outward.x, eta * d.x), std::fmaf(kk, outward.y, eta * d.y), std::fmaf(kk, outward.z, eta * d.z) };
+			float r0 = (1.0f - refl) / (1.0f + refl);
+			r0 = r0 * r0;
+			const double x = static_cast<double>(1.0f - cosine);
+			const double x2 = x * x;
+			const double x5 = (x2 * x2) * x;
+			reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
+		}
+		if (out_reflect_prob)
+			*out_reflect_prob = reflect_prob;
+		return (u < reflect_prob) ? reflected : refracted;
+	}
+
+	inline bool refracts_in_sm(uint32_t type) // sm_ray_tracer.cpp:229-233
+	{
+		return type == RT_HIP_MATERIAL_DIELECTRIC || type == RT_HIP_MATERIAL_AIR || type == RT_HIP_MATERIAL_VACUUM || type == RT_HIP_MATERIAL_WATER
+			|| type == RT_HIP_MATERIAL_ICE;
+	}
+
 	// scatter_funcs table, mg_ray_tracer.cpp:142-152: metal -> metal_scatter, everything else -> lambert_scatter
+	// (sm_ray_tracer.cpp:221-236 additionally sends dielectric/air/vacuum/water/ice to dielectric_scatter)
 	inline bool scatter(const frame& f, const ray& r, const hit_result& hit, random_stream& rng, ray& out, vec3& attenuation)
 	{
 		const material& m = f.materials[hit.material];
 		attenuation = m.attenuation;
 		if (m.type == RT_HIP_MATERIAL_METAL)
 			return metal_scatter(r, hit, m.roughness, rng, out);
+		if (f.sm_materials && refracts_in_sm(m.type))
+			return dielectric_scatter(r, hit, m.reflectivity, rng, out);
 		return lambert_scatter(r, hit, rng, out);
 	}
 
@@ -471,7 +541,7 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 							 uint32_t width,
 							 uint32_t height,
 							 uint64_t seed,
-							 int trace_order,
+							 int mode,
 							 const rt_hip_partition* part,
 							 uint32_t* rgba8,
 							 float* rgb_f32,
@@ -485,7 +555,7 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 	if (!p.world || p.rank >= p.world || !p.stripe_rows)
 		return 1;
 
-	const frame f = make_frame(scene, width, height, seed, trace_order);
+	const frame f = make_frame(scene, width, height, seed, mode);
 
 	// rows owned by this rank, in local order
 	std::vector<uint32_t> rows;
@@ -598,4 +668,12 @@ extern "C" void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, ui
 	out_dir[0] = r.dir.x;
 	out_dir[1] = r.dir.y;
 	out_dir[2] = r.dir.z;
+}
+
+extern "C" void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob)
+{
+	const vec3 r = dielectric_direction({ dir[0], dir[1], dir[2] }, { normal[0], normal[1], normal[2] }, reflectivity, u, out_reflect_prob);
+	out_dir[0] = r.x;
+	out_dir[1] = r.y;
+	out_dir[2] = r.z;
 }

@@ -31,11 +31,12 @@ typedef struct oracle_stats
 	double seconds; /* wall time of the render loop */
 } oracle_stats;
 
-/* trace() evaluation order */
+/* render mode bits */
 enum
 {
 	ORACLE_TRACE_ITERATIVE = 0, /* the arithmetic contract shared with the GPU (forward throughput product) */
-	ORACLE_TRACE_RECURSIVE = 1	/* literal recursion of mg_ray_tracer.cpp:155-174 (attenuation * trace(...)) */
+	ORACLE_TRACE_RECURSIVE = 1, /* literal recursion of mg_ray_tracer.cpp:155-174 (attenuation * trace(...)) */
+	ORACLE_MATERIALS_SM	   = 2	/* scatter table of sm_ray_tracer.cpp:221-236: dielectric/air/vacuum/water/ice refract */
 };
 
 /* Counter-RNG, strict IEEE render: the parity oracle.  rgba8 / rgb_f32 are local_rows x width (compact
@@ -45,7 +46,7 @@ int oracle_render(const rt_hip_scene* scene,
 				  uint32_t width,
 				  uint32_t height,
 				  uint64_t seed,
-				  int trace_order,
+				  int mode, /* ORACLE_* bits */
 				  const rt_hip_partition* part,
 				  uint32_t* rgba8,
 				  float* rgb_f32, /* nullable */
@@ -78,6 +79,8 @@ void oracle_closest_hit(const rt_hip_scene* scene,
 void oracle_sqrt_div(uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
 uint32_t oracle_pack(float r, float g, float b);			   /* rt::colour{vec3} -> uint32, colour.hpp:63-65,101-106 */
 void oracle_sky(float dir_y, float* out_rgb);				   /* mg_ray_tracer.cpp:164 */
+/* sm_ray_tracer.cpp:181-219: direction chosen by dielectric_scatter for the uniform number u; also the reflect probability */
+void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob);
 void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir);
 
 #ifdef __cplusplus

@@ -21,6 +21,7 @@ RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
 RT_HIP_FLAG_PERSISTENT_FRAME = 1 << 2
+RT_HIP_FLAG_SM_MATERIALS = 1 << 3
 KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small"}
 
 STATUS_NAMES = {

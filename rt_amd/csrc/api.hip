@@ -112,7 +112,7 @@ struct rt_hip_ctx
 	// the scene, resident in HBM: one buffer holding every column back to back (256-byte aligned starts)
 	device_buffer scene_columns;
 	device_scene scene{};
-	small_scene small{}; // host copy of the kernel-argument scene of the `small` kernel
+	small_scene small{}, small_sm{}; // host copies of the kernel-argument scene of the `small` kernel (mg / sm scatter tables)
 	bool have_scene = false;
 	uint32_t samples_per_pixel = 0, max_bounces = 0;
 	float inverse_view_projection[16]{};
@@ -327,6 +327,8 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	const size_t o_geometry = place(n_primitives * sizeof(float4));
 	const size_t o_prim_shading = place(n_primitives * sizeof(float4));
 	const size_t o_prim_metal = place(n_primitives * 4);
+	const size_t o_prim_shading_sm = place(n_primitives * sizeof(float4));
+	const size_t o_prim_scatter_sm = place(n_primitives * 4);
 	const size_t total = offset ? offset : column_alignment;
 
 	// host image of the block (one H2D copy)
@@ -359,6 +361,7 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	put(o_type, s.material_type, static_cast<size_t>(s.n_materials) * 4);
 	// derived per-primitive tables (spheres, then planes)
 	ctx->small = small_scene{};
+	ctx->small_sm = small_scene{};
 	for (size_t i = 0; i < n_primitives; i++)
 	{
 		const bool is_sphere = i < s.n_spheres;
@@ -378,15 +381,30 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 			geometry[3] = s.plane_d[k];
 			material = s.plane_material[k];
 		}
-		const uint32_t metal = s.material_type[material] == RT_HIP_MATERIAL_METAL ? 1u : 0u;
+		const uint32_t type = s.material_type[material];
+		const uint32_t metal = type == RT_HIP_MATERIAL_METAL ? scatter_metal : scatter_lambert; // mg_ray_tracer.cpp:142-152
+		// sm_ray_tracer.cpp:221-236
+		const bool refracts = type == RT_HIP_MATERIAL_DIELECTRIC || type == RT_HIP_MATERIAL_AIR || type == RT_HIP_MATERIAL_VACUUM
+						   || type == RT_HIP_MATERIAL_WATER || type == RT_HIP_MATERIAL_ICE;
+		const uint32_t scatter_sm = refracts ? scatter_dielectric : metal;
+		float shading_mg[4], shading_sm[4];
+		std::memcpy(shading_mg, host.data() + o_shading + material * sizeof(float4), sizeof(float4));
+		std::memcpy(shading_sm, shading_mg, sizeof(float4));
+		if (refracts)
+			shading_sm[3] = s.material_reflectivity[material]; // index of refraction instead of the (unused) roughness
 		put(o_geometry + i * sizeof(float4), geometry, sizeof(geometry));
-		std::memcpy(host.data() + o_prim_shading + i * sizeof(float4), host.data() + o_shading + material * sizeof(float4), sizeof(float4));
+		put(o_prim_shading + i * sizeof(float4), shading_mg, sizeof(float4));
 		put(o_prim_metal + i * 4, &metal, 4);
+		put(o_prim_shading_sm + i * sizeof(float4), shading_sm, sizeof(float4));
+		put(o_prim_scatter_sm + i * 4, &scatter_sm, 4);
 		if (is_sphere && i < scalar_max_spheres)
 		{
 			std::memcpy(&ctx->small.geometry[i], geometry, sizeof(geometry));
-			std::memcpy(&ctx->small.shading[i], host.data() + o_shading + material * sizeof(float4), sizeof(float4));
-			ctx->small.metal[i] = metal;
+			std::memcpy(&ctx->small.shading[i], shading_mg, sizeof(float4));
+			ctx->small.scatter[i] = metal;
+			std::memcpy(&ctx->small_sm.geometry[i], geometry, sizeof(geometry));
+			std::memcpy(&ctx->small_sm.shading[i], shading_sm, sizeof(float4));
+			ctx->small_sm.scatter[i] = scatter_sm;
 		}
 	}
 
@@ -421,7 +439,9 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	d.material_type = reinterpret_cast<const uint32_t*>(base + o_type);
 	d.primitive_geometry = reinterpret_cast<const float4*>(base + o_geometry);
 	d.primitive_shading = reinterpret_cast<const float4*>(base + o_prim_shading);
-	d.primitive_metal = reinterpret_cast<const uint32_t*>(base + o_prim_metal);
+	d.primitive_scatter = reinterpret_cast<const uint32_t*>(base + o_prim_metal);
+	d.primitive_shading_sm = reinterpret_cast<const float4*>(base + o_prim_shading_sm);
+	d.primitive_scatter_sm = reinterpret_cast<const uint32_t*>(base + o_prim_scatter_sm);
 
 	ctx->samples_per_pixel = s.samples_per_pixel;
 	ctx->max_bounces = s.max_bounces;
@@ -447,7 +467,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
 	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
-	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME))
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
 	if (!ctx->have_scene)
 		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
@@ -487,7 +507,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 
 	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
 	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
-	const uint32_t variant = launch_render(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	const uint32_t variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
 	ctx->render_recorded = true;

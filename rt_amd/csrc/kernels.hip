@@ -217,16 +217,17 @@ namespace rt_hip
 		}
 
 		// lookups of the winning primitive from the global per-primitive tables (one indexed read each)
+		template <bool SM>
 		__device__ __forceinline__ void
-		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, bool& metal)
+		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, uint32_t& scatter)
 		{
-			metal = false;
+			scatter = scatter_lambert;
 			if (kind) // normal and shading are meaningful only for a hit
 			{
 				const uint32_t primitive = kind == 1u ? index : s.n_spheres + index;
 				const float4 g = s.primitive_geometry[primitive];
-				shading = s.primitive_shading[primitive];
-				metal = s.primitive_metal[primitive] != 0;
+				shading = SM ? s.primitive_shading_sm[primitive] : s.primitive_shading[primitive];
+				scatter = SM ? s.primitive_scatter_sm[primitive] : s.primitive_scatter[primitive];
 				if (kind == 1u)
 					normal = normalize(ray_at(o, d, distance) - vec3{ g.x, g.y, g.z }); // (:85)
 				else
@@ -249,7 +250,8 @@ namespace rt_hip
 		// workgroup's four waves (coalesced dword per lane per column, radius squared on the way in); every wave still
 		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
 		// each tile, until all four queues are empty.
-		template <int NS>
+		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
+		template <int NS, bool SM>
 		__global__ __launch_bounds__(block_threads) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
@@ -273,7 +275,7 @@ namespace rt_hip
 					{
 						lds_geometry[i] = small.geometry[i];
 						lds_shading[i] = small.shading[i];
-						lds_metal[i] = small.metal[i];
+						lds_metal[i] = small.scatter[i];
 					}
 				}
 			}
@@ -399,7 +401,7 @@ namespace rt_hip
 				vec3 normal, base, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
 				float4 shading;
 				float spread = 1.0f;
-				bool metal = false;
+				uint32_t scatter_kind = scatter_lambert;
 				if (tracing)
 				{
 					st.bounces_left--; // `if (!(max_bounces--)) return {}` (:157) is checked when the bounce is made, below
@@ -410,7 +412,7 @@ namespace rt_hip
 					{
 						uint32_t index;
 						kind = select_hit(tiled_spheres, tiled_planes, distance, index);
-						fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+						fetch_hit<SM>(s, st.origin, st.dir, kind, distance, index, normal, shading, scatter_kind);
 					}
 					else if (NS > 0)
 					{
@@ -425,7 +427,7 @@ namespace rt_hip
 						{
 							const float4 g = lds_geometry[best.index];
 							shading = lds_shading[best.index];
-							metal = lds_metal[best.index] != 0;
+							scatter_kind = lds_metal[best.index];
 							normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z }); // (:85)
 						}
 					}
@@ -437,7 +439,7 @@ namespace rt_hip
 						scan_lds<true>(spheres, st.origin, st.dir, lds, s.n_spheres, 0);
 						uint32_t index;
 						kind = select_hit(spheres, planes, distance, index);
-						fetch_hit(s, st.origin, st.dir, kind, distance, index, normal, shading, metal);
+						fetch_hit<SM>(s, st.origin, st.dir, kind, distance, index, normal, shading, scatter_kind);
 					}
 					if (!kind)
 						end_sample(st.throughput * sky(st.dir.y)); // miss (:163-164)
@@ -446,7 +448,7 @@ namespace rt_hip
 						shade = true;
 						hit_pos = ray_at(st.origin, st.dir, distance);
 						base = normal;
-						if (metal)
+						if (scatter_kind == scatter_metal)
 						{
 							// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
 							const vec3 v = normalize(st.dir);
@@ -467,8 +469,46 @@ namespace rt_hip
 					float d1 = next_random(counter);
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
 					bool absorbed = false;
-					if (shade)
+					bool unit_length = false; // `toward` is used as it is (sm's dielectric_scatter does not normalise)
+					if (shade && SM && scatter_kind == scatter_dielectric)
 					{
+						// dielectric_scatter, sm_ray_tracer.cpp:181-219 (refract :161-172, schlick :174-179); shading.w = the
+						// material's reflectivity, which the reference uses as the index of refraction.  ONE draw.
+						const float refl = shading.w;
+						const vec3 d = st.dir;
+						const float dn = dot(d, normal);
+						const float k = 2.0f * dn;
+						const vec3 reflected = { fma(-k, normal.x, d.x), fma(-k, normal.y, d.y), fma(-k, normal.z, d.z) };
+						const float len = __builtin_sqrtf(dot(d, d));
+						const bool inside = dn > 0.0f;
+						const vec3 outward = inside ? vec3{ -normal.x, -normal.y, -normal.z } : normal;
+						const float eta = inside ? refl : 1.0f / refl;
+						const float cosine = inside ? (refl * dn) / len : (-dn) / len;
+						float reflect_prob = 1.0f;
+						vec3 refracted = { 0.0f, 0.0f, 0.0f };
+						const float cos_i = -dot(d, outward);
+						const float sin2_t = (eta * eta) * fma(-cos_i, cos_i, 1.0f);
+						if (!(sin2_t > 1.0f)) // refract() returned true
+						{
+							const float cos_t = __builtin_sqrtf(1.0f - sin2_t);
+							const float kk = fma(eta, cos_i, -cos_t);
+							refracted = { fma(kk, outward.x, eta * d.x), fma(kk, outward.y, eta * d.y), fma(kk, outward.z, eta * d.z) };
+							float r0 = (1.0f - refl) / (1.0f + refl);
+							r0 = r0 * r0;
+							const double x = static_cast<double>(1.0f - cosine); // pow(1 - cosine, 5) in double, by multiplication
+							const double x2 = x * x;
+							const double x5 = (x2 * x2) * x;
+							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
+						}
+						counter = counter_at_start + draw_stride; // only d0 was consumed
+						toward = (d0 < reflect_prob) ? reflected : refracted;
+						unit_length = true;
+						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
+						st.origin = hit_pos;
+					}
+					else if (shade)
+					{
+						const bool metal = scatter_kind == scatter_metal;
 						float d2 = next_random(counter);
 						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
 						{
@@ -527,7 +567,13 @@ namespace rt_hip
 					if (shade || restart)
 					{
 						st.counter = counter;
-						st.dir = normalize(toward);
+						if (SM)
+						{
+							const vec3 unit = normalize(unit_length ? vec3{ 0.0f, 0.0f, 1.0f } : toward);
+							st.dir = unit_length ? toward : unit;
+						}
+						else
+							st.dir = normalize(toward);
 					}
 					// absorbed, or the next trace() call would return {} at :157-158: the sample is worth nothing
 					if (shade && (absorbed || st.bounces_left == 0))
@@ -629,8 +675,8 @@ namespace rt_hip
 				const uint32_t kind = select_hit(spheres, planes, distance, index);
 				vec3 normal;
 				float4 shading;
-				bool metal;
-				fetch_hit(s, o, d, kind, distance, index, normal, shading, metal);
+				uint32_t scatter;
+				fetch_hit<false>(s, o, d, kind, distance, index, normal, shading, scatter);
 				if (!kind)
 					normal = { 0.0f, 0.0f, 0.0f }; // hit_result{ -1 } of the reference: no normal
 				out_distance[i] = distance;
@@ -689,8 +735,24 @@ namespace rt_hip
 				}
 		}
 
+		template <int NS, bool SM>
+		void launch_queue_sm(const frame_params& frame,
+							 const queue_params& queue,
+							 const small_scene& small,
+							 const device_scene& scene,
+							 dim3 grid,
+							 size_t lds_bytes,
+							 uint32_t* d_rgba8,
+							 float* d_rgb_f32,
+							 device_counters* d_counters,
+							 hipStream_t stream)
+		{
+			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, d_rgba8, d_rgb_f32, d_counters);
+		}
+
 		template <int NS>
-		void launch_queue(const frame_params& frame,
+		void launch_queue(bool sm,
+						  const frame_params& frame,
 						  const queue_params& queue,
 						  const small_scene& small,
 						  const device_scene& scene,
@@ -701,7 +763,10 @@ namespace rt_hip
 						  device_counters* d_counters,
 						  hipStream_t stream)
 		{
-			hipLaunchKernelGGL(render_queue<NS>, grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, d_rgba8, d_rgb_f32, d_counters);
+			if (sm)
+				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			else
+				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 		}
 	}
 
@@ -746,6 +811,7 @@ namespace rt_hip
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
+		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, static_cast<uint64_t>(frame.width) * frame.local_rows);
 		const uint32_t tile_w = 1u << queue.tile_w_log2;
 		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
@@ -756,24 +822,24 @@ namespace rt_hip
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
 			switch (scene.n_spheres)
 			{
-				case 1: launch_queue<1>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 2: launch_queue<2>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 3: launch_queue<3>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 4: launch_queue<4>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 5: launch_queue<5>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 6: launch_queue<6>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 7: launch_queue<7>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				default: launch_queue<8>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
 			}
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
 			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
-			launch_queue<0>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 			return variant;
 		}
-		launch_queue<-1>(frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 		return variant;
 	}
 

@@ -31,7 +31,18 @@ namespace rt_hip
 		// derived per-primitive tables; spheres first, then planes (index n_spheres + i)
 		const float4* primitive_geometry; // sphere: (cx, cy, cz, r*r); plane: (nx, ny, nz, d)
 		const float4* primitive_shading;  // (attenuation.rgb, roughness) of the primitive's material
-		const uint32_t* primitive_metal;  // 1 if the primitive's material is metal, else 0
+		const uint32_t* primitive_scatter; // scatter function of the primitive's material: scatter_lambert / scatter_metal
+		// the same two tables under sm_ray_tracer's scatter table (RT_HIP_FLAG_SM_MATERIALS): dielectric, air, vacuum, water
+		// and ice become scatter_dielectric, and their shading.w carries the reflectivity (= index of refraction)
+		const float4* primitive_shading_sm;
+		const uint32_t* primitive_scatter_sm;
+	};
+
+	enum : uint32_t
+	{
+		scatter_lambert = 0,	// mg_ray_tracer.cpp:110-123
+		scatter_metal = 1,		// mg_ray_tracer.cpp:126-140
+		scatter_dielectric = 2	// sm_ray_tracer.cpp:181-219 (opt-in)
 	};
 
 	// Per-frame uniforms (kernel arguments -> SGPRs).
@@ -59,8 +70,8 @@ namespace rt_hip
 	struct small_scene
 	{
 		float4 geometry[scalar_max_spheres]; // (center, radius^2)
-		float4 shading[scalar_max_spheres];	 // (attenuation.rgb, roughness) of the sphere's material
-		uint32_t metal[scalar_max_spheres];
+		float4 shading[scalar_max_spheres];	 // (attenuation.rgb, roughness or index of refraction) of the sphere's material
+		uint32_t scatter[scalar_max_spheres]; // scatter_*
 	};
 
 	// pixel sums are taken in chunks of this many consecutive samples (arithmetic contract; see oracle/cpu_ref.cpp)
@@ -89,7 +100,7 @@ namespace rt_hip
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,
 						   const device_scene& scene,
-						   const small_scene& small, // valid when choose_kernel() says RT_HIP_KERNEL_SMALL
+						   const small_scene& small, // valid when choose_kernel() says RT_HIP_KERNEL_SMALL; tables already chosen by flag
 						   uint32_t flags,
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,

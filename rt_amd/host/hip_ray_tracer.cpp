@@ -23,13 +23,15 @@ using namespace rt;
 
 namespace
 {
-	struct hip_ray_tracer final : renderer_interface
+	// SmMaterials = false: mg_ray_tracer's scatter table; true: sm_ray_tracer's (dielectrics refract), see RT_HIP_FLAG_SM_MATERIALS
+	template <bool SmMaterials>
+	struct hip_renderer : renderer_interface
 	{
 		rt_hip_ctx* ctx = nullptr;
 		bool failed_to_create = false;
 		uint64_t frame_number = 0;
 
-		~hip_ray_tracer() noexcept override { rt_hip_destroy(ctx); }
+		~hip_renderer() noexcept override { rt_hip_destroy(ctx); }
 
 		void render(const rt::scene& scene, image_view& pixels, muu::thread_pool& /*threads*/) noexcept override
 		{
@@ -76,10 +78,16 @@ namespace
 			const char* fixed = std::getenv("RT_HIP_SEED");
 			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
 
-			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, RT_HIP_FLAG_PERSISTENT_FRAME, nullptr, nullptr) != RT_HIP_OK)
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME) | (SmMaterials ? static_cast<uint32_t>(RT_HIP_FLAG_SM_MATERIALS) : 0u), nullptr, nullptr) != RT_HIP_OK)
 				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
 		}
 	};
 
+	struct hip_ray_tracer final : hip_renderer<false>
+	{};
+	struct hip_sm_ray_tracer final : hip_renderer<true>
+	{};
+
 	REGISTER_RENDERER(hip_ray_tracer);
+	REGISTER_RENDERER(hip_sm_ray_tracer);
 }

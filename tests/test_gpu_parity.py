@@ -177,6 +177,26 @@ def test_sphere_counts_around_the_scalar_kernel_limit(tracer, count):
     assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{count} spheres")
 
 
+SM = capi.RT_HIP_FLAG_SM_MATERIALS
+
+
+@pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED], ids=["auto", "resident", "tiled"])
+@pytest.mark.parametrize("name,width,height,spp,seed", [("dielectric", 192, 108, 12, 21), ("dielectric", 64, 36, 40, 22), ("basic", 96, 54, 6, 23), ("planes", 96, 54, 6, 24)])
+def test_sm_material_table_is_bit_exact(tracer, planes_scene, name, width, height, spp, seed, flags):
+    """Opt-in RT_HIP_FLAG_SM_MATERIALS: sm_ray_tracer's scatter table (dielectric_scatter for dielectric / air /
+    vacuum / water / ice, reference src/renderers/sm_ray_tracer.cpp:181-236) against the oracle in the same mode."""
+    scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
+    scene.set_sampling(spp, 10)
+    pod = scene.describe(width, height)
+    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags | SM, want_rgb=True)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed, sm_materials=True)
+    assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"sm {name} {width}x{height}x{spp} ({stats['kernel']})")
+    assert stats["segments"] == want_stats["segments"]
+    if name == "dielectric":  # and it really is a different image from the mg one
+        mg_rgba, _, _ = tracer.render(pod, width, height, seed=seed, flags=flags)
+        assert not np.array_equal(mg_rgba, got_rgba)
+
+
 def test_empty_scene_renders_sky(tracer):
     ivp = rt_amd.Scene.named("basic").describe(40, 24).inverse_view_projection[:]
     pod = rt_amd.scene_from_arrays(samples_per_pixel=3, max_bounces=2, inverse_view_projection=ivp)

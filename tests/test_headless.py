@@ -17,7 +17,7 @@ def run(*args, **kw):
 def test_list_shows_the_registered_renderers():
     out = run("--list")
     assert out.returncode == 0
-    assert "hip_ray_tracer" in out.stdout and "null_renderer" in out.stdout
+    assert "hip_ray_tracer" in out.stdout and "hip_sm_ray_tracer" in out.stdout and "null_renderer" in out.stdout
 
 
 def test_unknown_renderer_and_missing_scene_fail_like_the_reference():
@@ -50,4 +50,20 @@ def test_hip_ray_tracer_plugin_renders_the_oracle_frame(tmp_path):
     got = np.frombuffer(data[len(header) :], dtype=np.uint8).reshape(54, 96, 3)
     scene = rt_amd.Scene.named("basic").set_sampling(5)
     want, _, _ = oracle.render(scene.describe(96, 54), 96, 54, seed=11, want_rgb=False)
+    assert np.array_equal(got, unpack(want)[..., :3])
+
+
+@pytest.mark.gpu
+def test_hip_sm_ray_tracer_plugin_renders_the_oracle_frame_in_sm_mode(tmp_path):
+    import rt_amd
+    from oracle import binding as oracle
+    from tests.conftest import unpack
+
+    ppm = tmp_path / "frame.ppm"
+    out = run("--renderer", "hip_sm", "--scene", "dielectric.toml", "--size", "80x45", "--spp", "6", "--seed", "5", "--out", str(ppm))
+    assert out.returncode == 0 and "created renderer: hip_sm_ray_tracer" in out.stdout and "error:" not in out.stderr
+    header = b"P6\n80 45\n255\n"
+    got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(45, 80, 3)
+    scene = rt_amd.Scene.named("dielectric").set_sampling(6)
+    want, _, _ = oracle.render(scene.describe(80, 45), 80, 45, seed=5, want_rgb=False, sm_materials=True)
     assert np.array_equal(got, unpack(want)[..., :3])

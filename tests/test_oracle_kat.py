@@ -307,3 +307,47 @@ def test_monte_carlo_error_falls_as_one_over_sqrt_spp():
     # sample 0 of every pixel is the un-jittered centre ray (mg_ray_tracer.cpp:189), so low-spp images carry a small
     # aliasing bias at silhouettes on top of the 1/sqrt(spp) noise: allow for it
     assert 1.4 < errs[0] / errs[1] < 2.6 and 1.4 < errs[1] / errs[2] < 2.6, errs
+
+
+# ---- opt-in: sm_ray_tracer's dielectric scatter (reference src/renderers/sm_ray_tracer.cpp:156-219) ---------------------------
+def test_dielectric_refraction_obeys_snells_law():
+    n = np.array([0.0, 1.0, 0.0])
+    for ior in (1.31, 1.333, 1.52):
+        for theta in (0.0, 0.3, 0.8, 1.2):
+            d = np.array([math.sin(theta), -math.cos(theta), 0.0])  # coming down onto the surface from outside
+            out, prob = oracle.dielectric_direction(d, n, ior, u=1.0)  # u = 1 never reflects (prob <= 1... u < prob false)
+            # refracted: sin(theta_t) = sin(theta_i) / ior, continuing downward
+            assert out[1] < 0
+            assert math.isclose(out[0] / np.linalg.norm(out), math.sin(theta) / ior, abs_tol=2e-6)
+            assert math.isclose(np.linalg.norm(out), 1.0, abs_tol=2e-6)
+            # Schlick: r0 + (1 - r0) (1 - cos)^5, reference sm_ray_tracer.cpp:174-179
+            r0 = ((1 - ior) / (1 + ior)) ** 2
+            assert math.isclose(prob, r0 + (1 - r0) * (1 - math.cos(theta)) ** 5, rel_tol=1e-5)
+            # u = 0 always reflects: mirror direction
+            refl, _ = oracle.dielectric_direction(d, n, ior, u=0.0)
+            assert np.allclose(refl, d - 2 * (d @ n) * n, atol=1e-6)
+
+
+def test_dielectric_total_internal_reflection_and_vacuum():
+    n = np.array([0.0, 1.0, 0.0])
+    # inside glass going up at a grazing angle: sin2_t > 1 -> reflect_prob = 1, always reflected
+    d = np.array([math.sin(1.2), math.cos(1.2), 0.0])
+    out, prob = oracle.dielectric_direction(d, n, 1.52, u=0.999)
+    assert prob == 1.0 and np.allclose(out, d - 2 * (d @ n) * n, atol=1e-6)
+    # vacuum (index 1): straight through at any angle unless the Schlick term fires
+    d = np.array([0.6, -0.8, 0.0])
+    out, prob = oracle.dielectric_direction(d, n, 1.0, u=0.5)
+    assert np.allclose(out, d, atol=1e-6) and math.isclose(prob, (1 - 0.8) ** 5, rel_tol=1e-5)
+
+
+def test_sm_material_mode_only_changes_refracting_materials():
+    scene = rt_amd.Scene.named("basic").set_sampling(4)  # lambert + metal only
+    pod = scene.describe(64, 36)
+    a, a_rgb, _ = oracle.render(pod, 64, 36, seed=9)
+    b, b_rgb, _ = oracle.render(pod, 64, 36, seed=9, sm_materials=True)
+    assert np.array_equal(a, b) and np.array_equal(a_rgb, b_rgb)
+    scene = rt_amd.Scene.named("dielectric").set_sampling(4)
+    pod = scene.describe(64, 36)
+    a, _, _ = oracle.render(pod, 64, 36, seed=9)
+    b, b_rgb, _ = oracle.render(pod, 64, 36, seed=9, sm_materials=True)
+    assert not np.array_equal(a, b) and np.isfinite(b_rgb).all()
