@@ -158,6 +158,14 @@ def hip_lib() -> C.CDLL:
     """The HIP module.  Raises if it has not been built — there is no fallback."""
     global _hip_lib
     if _hip_lib is None:
+        # PyTorch-ROCm ships its own copy of the HIP runtime.  A process that is going to use both (bench.py, the
+        # multi-GPU path, some tests) must let torch load its copy FIRST: if librt_hip.so pulls in /opt/rocm's runtime
+        # before `import torch`, torch later finds "No HIP GPUs".  Loading torch here pins the order for the harness;
+        # C++ users of librt_hip.so (rt itself, rt_headless) never see torch.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = hip_library_path()
         if not path.exists():
             raise RtHipError(2, f"{path} not found: build it with `make` (or __graft_entry__.build())")

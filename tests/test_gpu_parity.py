@@ -288,9 +288,15 @@ def test_partition_invariance_and_device_assemble(tracer, world, stripe):
 
 # ---- BASELINE.json's full sizes -----------------------------------------------------------------------------------------------
 def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
-    """Render the full frame on the GPU; bit-check one stripe subset (rank 0 of `oracle_world`) against the oracle;
-    check the rest through properties."""
+    """Render the full frame on the GPU; bit-check it against the oracle — the WHOLE frame when the host has the
+    cores to render it in seconds (the GPU boxes do: the oracle runs at >100 Mrays/s there), otherwise the stripe
+    subset `rank 0 of oracle_world`; check the rest through properties."""
+    import os
+
     import torch
+
+    if len(os.sched_getaffinity(0)) >= 64:
+        oracle_world = 1
 
     pod = scene.describe(width, height)
     tracer.upload(pod)
@@ -343,8 +349,12 @@ def test_headline_basic_1080p_256spp(tracer):
 
 
 def test_config4_basic_4k_tile_split(tracer):
-    """BASELINE config 4's frame (3840x2160) at reduced spp: every rank's part of the 8-way split, assembled."""
-    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(8), 3840, 2160, seed=1, oracle_world=16)
+    """BASELINE config 4's frame (3840x2160), every rank's part of the 8-way split assembled on the device; at the full
+    256 spp when the host can render the oracle frame in seconds (2.1 G samples), at 8 spp otherwise."""
+    import os
+
+    spp = 256 if len(os.sched_getaffinity(0)) >= 64 else 8
+    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(spp), 3840, 2160, seed=1, oracle_world=16)
 
 
 def test_config5_synthetic_100k_tiled(tracer):
