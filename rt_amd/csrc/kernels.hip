@@ -251,8 +251,9 @@ namespace rt_hip
 		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
 		// each tile, until all four queues are empty.
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
+		// launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs — the scans are latency-bound chains and want the waves
 		template <int NS, bool SM>
-		__global__ __launch_bounds__(block_threads) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, 8) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
@@ -325,52 +326,11 @@ namespace rt_hip
 
 			while (true)
 			{
-				// ---- hand out items to free lanes (converged) ---------------------------------------------------------
-				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
-				if (asking != 0)
-				{
-					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
-					if (mode == lane_free)
-					{
-						item = next_item + rank;
-						if (item >= items)
-							mode = lane_retired;
-						else
-						{
-							const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
-							const uint32_t chunk = item >> q.pixels_log2;
-							const uint32_t lx = tile_x0 + (pixel & (tile_w - 1u));
-							const uint32_t ly = tile_y0 + (pixel >> q.tile_w_log2);
-							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
-							if (lx < p.width && ly < p.local_rows)
-							{
-								const uint32_t gy = global_row(ly, p);
-								st.fx = static_cast<float>(lx);
-								st.fy = static_cast<float>(gy);
-								st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
-								st.sample = chunk * sample_chunk;
-								st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
-								mode = lane_restart;
-							}
-							// else: a pixel outside the frame — the item is empty, ask again next trip
-						}
-					}
-					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
-				}
-				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
-				if (NS < 0)
-				{
-					if (__syncthreads_and(queue_empty)) // the four waves leave together
-						break;
-				}
-				else if (queue_empty)
-					break;
-
 				// ---- closest-hit query for every lane that holds a ray (trace(), :160-162) -----------------------------------
 				const bool tracing = mode == lane_trace;
 				candidate tiled_planes = { 0.0f, 0u, false };
 				candidate tiled_spheres = { 0.0f, 0u, false };
-				if (NS < 0)
+				if (NS < 0 && __syncthreads_or(tracing)) // nothing to stream on the very first trip: no lane holds a ray yet
 				{
 					// all 256 threads stage, lanes without a ray just do not scan
 					for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
@@ -458,6 +418,48 @@ namespace rt_hip
 						}
 					}
 				}
+
+
+				// ---- hand out items to free lanes (converged): a lane whose chunk just ended with a miss restarts right below ----
+				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
+				if (asking != 0)
+				{
+					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
+					if (mode == lane_free)
+					{
+						item = next_item + rank;
+						if (item >= items)
+							mode = lane_retired;
+						else
+						{
+							const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
+							const uint32_t chunk = item >> q.pixels_log2;
+							const uint32_t lx = tile_x0 + (pixel & (tile_w - 1u));
+							const uint32_t ly = tile_y0 + (pixel >> q.tile_w_log2);
+							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+							if (lx < p.width && ly < p.local_rows)
+							{
+								const uint32_t gy = global_row(ly, p);
+								st.fx = static_cast<float>(lx);
+								st.fy = static_cast<float>(gy);
+								st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+								st.sample = chunk * sample_chunk;
+								st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+								mode = lane_restart;
+							}
+							// else: a pixel outside the frame — the item is empty, ask again next trip
+						}
+					}
+					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
+				}
+				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
+				if (NS < 0)
+				{
+					if (__syncthreads_and(queue_empty)) // the four waves leave together
+						break;
+				}
+				else if (queue_empty)
+					break;
 
 				const bool restart = mode == lane_restart;
 				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
@@ -782,7 +784,7 @@ namespace rt_hip
 		return RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels, bool tiled)
 	{
 		// K chunks per pixel; P pixels per wave.  A queue of about 256 items (4 per lane) keeps the lanes of a wave
 		// evenly busy; a launch also wants several tens of thousands of waves to balance over 1024 SIMDs, so smaller
@@ -792,7 +794,8 @@ namespace rt_hip
 		uint32_t pixels_log2 = 6; // 64 pixels = 8 x 8
 		while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
 			pixels_log2--;
-		if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
+		// (the tiled kernel's workgroups advance in lock step and are long-lived either way: they keep the full queues)
+		if (!tiled && pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
 			pixels_log2--;
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 8x8, 8x4, 4x4, 4x2, 2x2
@@ -812,7 +815,7 @@ namespace rt_hip
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, static_cast<uint64_t>(frame.width) * frame.local_rows);
+		const queue_params queue = choose_queue(frame.samples_per_pixel, static_cast<uint64_t>(frame.width) * frame.local_rows, variant == RT_HIP_KERNEL_TILED);
 		const uint32_t tile_w = 1u << queue.tile_w_log2;
 		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
 		const dim3 grid((frame.width + 4u * tile_w - 1u) / (4u * tile_w), (frame.local_rows + tile_h - 1u) / tile_h);

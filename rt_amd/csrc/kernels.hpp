@@ -84,7 +84,7 @@ namespace rt_hip
 		uint32_t pixels_log2; // a wave owns P = 2^pixels_log2 pixels (a tile of 2^tile_w_log2 columns)
 		uint32_t tile_w_log2;
 	};
-	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels);
+	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels, bool tiled);
 
 	struct device_counters
 	{
