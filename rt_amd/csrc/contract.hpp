@@ -126,10 +126,27 @@ namespace rt_hip
 		return q;
 	}
 
+	// inv_sqrt_rn for an argument the CALLER has proved to lie in the band: no check, no fallback
+	__device__ __forceinline__ float inv_sqrt_in_band(float x)
+	{
+		float h;
+		const float s = sqrt_core(x, h);
+		return rcp_core(s, __builtin_amdgcn_rcpf(s));
+	}
+
 	// normalize(v) = v * (1 / sqrt(dot(v,v)))
 	__device__ __forceinline__ vec3 normalize(vec3 v)
 	{
 		const float inv = inv_sqrt_rn(dot(v, v));
+		return v * inv;
+	}
+
+	// normalize() of a random_unit_vector() candidate (random.hpp:57-66): components are multiples of 2^-24 in [0, 1),
+	// not all zero, so dot(v,v) >= 2^-48 (a sum of non-negative terms is never rounded below its largest term) and < 3:
+	// always inside the band
+	__device__ __forceinline__ vec3 normalize_unit_cube_draw(vec3 v)
+	{
+		const float inv = inv_sqrt_in_band(dot(v, v));
 		return v * inv;
 	}
 
@@ -176,7 +193,7 @@ namespace rt_hip
 			z = next_random(counter);
 		}
 		while (x == 0.0f && y == 0.0f && z == 0.0f);
-		return normalize({ x, y, z });
+		return normalize_unit_cube_draw({ x, y, z });
 	}
 
 	// ---- intersection (muu::ray::hits) --------------------------------------------------------

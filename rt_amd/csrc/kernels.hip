@@ -518,7 +518,7 @@ namespace rt_hip
 							d1 = next_random(counter);
 							d2 = next_random(counter);
 						}
-						const vec3 u = normalize({ d0, d1, d2 });
+						const vec3 u = normalize_unit_cube_draw({ d0, d1, d2 });
 						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
 						vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
 						if (metal)

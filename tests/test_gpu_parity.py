@@ -180,6 +180,46 @@ def test_sphere_counts_around_the_scalar_kernel_limit(tracer, count):
 SM = capi.RT_HIP_FLAG_SM_MATERIALS
 
 
+def random_scene(rng):
+    """A random rt scene: 0-12 spheres (one may contain the camera), 0-3 planes, 1-5 materials of every kind with
+    random albedo / roughness / reflectivity, random camera pose, spp and bounce limit."""
+    n_mat = int(rng.integers(1, 6))
+    materials = []
+    for _ in range(n_mat):
+        kind = int(rng.integers(0, 8))
+        materials.append((kind, *rng.uniform(0.1, 1.0, 3), 1.0, rng.uniform(0.0, 0.6), rng.uniform(0.3, 1.6)))
+    n_s = int(rng.integers(0, 13))
+    spheres = [(rng.uniform(-4, 4), rng.uniform(-1, 3), rng.uniform(-8, 0), rng.uniform(0.2, 1.5), rng.integers(0, n_mat)) for _ in range(n_s)]
+    if n_s and rng.random() < 0.3:
+        spheres[0] = (0.0, 1.0, 2.0, 30.0, spheres[0][4])  # a sphere around the camera: rays start inside it
+    planes = []
+    for _ in range(int(rng.integers(0, 4))):
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        planes.append((*n, rng.uniform(0.0, 3.0), rng.integers(0, n_mat)))
+    camera = rt_amd.Scene.parse("").set_camera((rng.uniform(-1, 1), rng.uniform(0.5, 2), rng.uniform(1, 4)), (rng.uniform(-0.3, 0.3), rng.uniform(-0.4, 0.2), -1.0))
+    return spheres, planes, materials, camera
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_scenes_are_bit_exact(tracer, case):
+    rng = np.random.default_rng(1000 + case)
+    spheres, planes, materials, camera = random_scene(rng)
+    width, height = int(rng.integers(17, 140)), int(rng.integers(9, 90))
+    spp, bounces = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
+    seed = int(rng.integers(0, 2**63))
+    for flags in (0, FORCE_RESIDENT, FORCE_TILED, SM):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed, sm_materials=bool(flags & SM))
+        # NaNs (e.g. from a ray that starts exactly on a degenerate configuration) must agree in place, any payload
+        same = (got_rgb.view(np.uint32) == want_rgb.view(np.uint32)) | (np.isnan(got_rgb) & np.isnan(want_rgb))
+        assert same.all(), f"case {case} flags {flags} ({stats['kernel']}): {(~same).any(axis=-1).sum()} pixels differ"
+        assert np.array_equal(got_rgba, want_rgba), f"case {case} flags {flags}"
+        assert stats["segments"] == want_stats["segments"]
+
+
 @pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED], ids=["auto", "resident", "tiled"])
 @pytest.mark.parametrize("name,width,height,spp,seed", [("dielectric", 192, 108, 12, 21), ("dielectric", 64, 36, 40, 22), ("basic", 96, 54, 6, 23), ("planes", 96, 54, 6, 24)])
 def test_sm_material_table_is_bit_exact(tracer, planes_scene, name, width, height, spp, seed, flags):
