@@ -471,6 +471,8 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
 	if (!ctx->have_scene)
 		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
+	if (height > 65535u * 2u) // the launch grid's y dimension counts pixel tiles at least two rows high
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: frame height %u exceeds the supported 131070 rows", height);
 	const rt_hip_partition whole = { 0, 1, RT_HIP_DEFAULT_STRIPE_ROWS };
 	const rt_hip_partition p = part ? *part : whole;
 	if (!valid_partition(p))
