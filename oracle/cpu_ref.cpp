@@ -526,15 +526,6 @@ namespace
 		colour = { std::sqrt(colour.x), std::sqrt(colour.y), std::sqrt(colour.z) }; // :196-198
 		out_rgba = pack(colour);													 // :200
 	}
-
-	inline uint32_t local_rows_of(uint32_t height, uint32_t rank, uint32_t world, uint32_t stripe)
-	{
-		uint32_t rows = 0;
-		for (uint32_t y0 = 0, b = 0; y0 < height; y0 += stripe, b++)
-			if (b % world == rank)
-				rows += (height - y0 < stripe) ? height - y0 : stripe;
-		return rows;
-	}
 }
 
 extern "C" int oracle_render(const rt_hip_scene* scene,
@@ -602,7 +593,6 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 		stats->plane_tests = stats->segments * scene->n_planes;
 		stats->seconds = std::chrono::duration<double>(t1 - t0).count();
 	}
-	(void)local_rows_of;
 	return 0;
 }
 

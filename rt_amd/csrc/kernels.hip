@@ -265,7 +265,7 @@ namespace rt_hip
 			// [NS > 0] 8 geometry + 8 shading float4s, 8 metal flags | [NS == 0] all primitives; then the chunk slots
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
-			uint32_t* const lds_metal = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
+			uint32_t* const lds_scatter = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
 			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (NS == 0 ? s.n_spheres + s.n_planes : tile_primitives);
 			if (NS > 0)
 			{
@@ -276,7 +276,7 @@ namespace rt_hip
 					{
 						lds_geometry[i] = small.geometry[i];
 						lds_shading[i] = small.shading[i];
-						lds_metal[i] = small.scatter[i];
+						lds_scatter[i] = small.scatter[i];
 					}
 				}
 			}
@@ -387,7 +387,7 @@ namespace rt_hip
 						{
 							const float4 g = lds_geometry[best.index];
 							shading = lds_shading[best.index];
-							scatter_kind = lds_metal[best.index];
+							scatter_kind = lds_scatter[best.index];
 							normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z }); // (:85)
 						}
 					}
