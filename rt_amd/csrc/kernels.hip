@@ -376,10 +376,26 @@ namespace rt_hip
 					}
 					else if (NS > 0)
 					{
+						// all NS discriminants first (independent straight-line code with scalar operands), one branch for
+						// "no lane can hit anything", then the square-root halves in index order
 						candidate best = { 0.0f, 0u, false };
+						constexpr int slots_ns = NS > 0 ? NS : 1; // (this branch is compiled, though never taken, for NS <= 0)
+						sphere_probe probes[slots_ns];
+						unsigned long long lanes[slots_ns];
+						unsigned long long any_lane = 0;
 #pragma unroll
 						for (int i = 0; i < NS; i++)
-							test_sphere(best, st.origin, st.dir, small.geometry[i], static_cast<uint32_t>(i)); // SGPR operands
+						{
+							probes[i] = probe_sphere(st.origin, st.dir, small.geometry[i]); // SGPR operands
+							lanes[i] = __builtin_amdgcn_ballot_w64(probes[i].pos);
+							any_lane |= lanes[i];
+						}
+						if (any_lane != 0)
+						{
+#pragma unroll
+							for (int i = 0; i < NS; i++)
+								finish_sphere(best, probes[i], small.geometry[i].w, static_cast<uint32_t>(i), lanes[i]);
+						}
 						const bool hit = best.have && best.t >= 0.0f;
 						kind = hit ? 1u : 0u;
 						distance = best.t;

@@ -201,7 +201,10 @@ def random_scene(rng):
     return spheres, planes, materials, camera
 
 
-@pytest.mark.parametrize("case", range(24))
+RANDOM_CASES = int(__import__("os").environ.get("RT_HIP_RANDOM_CASES", "24"))  # a soak run sets this to hundreds
+
+
+@pytest.mark.parametrize("case", range(RANDOM_CASES))
 def test_random_scenes_are_bit_exact(tracer, case):
     rng = np.random.default_rng(1000 + case)
     spheres, planes, materials, camera = random_scene(rng)
