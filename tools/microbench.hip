@@ -77,6 +77,44 @@ __global__ __launch_bounds__(256) void bench_pk(float* out, float seed)
 		out[0] = s;
 }
 
+// Issue-port experiment: the same FMA work as plain (2-cycle) or packed (4-cycle) instructions, interleaved with S
+// scalar instructions per 8 lane-FMAs.  If scalar and vector instructions compete for issue slots, the packed form
+// (half as many vector instructions) should lose less to the scalar ones.
+template <int SCALAR_OPS, bool PACKED>
+__global__ __launch_bounds__(256) void bench_mixed(float* out, float seed)
+{
+	float2v v[4];
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		v[i] = float2v{ seed + threadIdx.x * 0.001f + i, seed + i * 0.5f };
+	const float2v a = { 1.0001f, 0.9999f }, b = { 0.5f, 0.25f };
+	unsigned s0 = blockIdx.x, s1 = 3;
+	for (int it = 0; it < ITER; it++)
+	{
+#pragma unroll
+		for (int i = 0; i < 4; i++)
+		{
+			if (PACKED)
+				v[i] = __builtin_elementwise_fma(v[i], a, b);
+			else
+			{
+				v[i].x = __builtin_fmaf(v[i].x, a.x, b.x);
+				asm volatile("" : "+v"(v[i].x)); // keep hipcc from re-packing the pair
+				v[i].y = __builtin_fmaf(v[i].y, a.y, b.y);
+				asm volatile("" : "+v"(v[i].y));
+			}
+			if (i < SCALAR_OPS)
+				asm volatile("s_add_u32 %0, %0, %1\n\ts_xor_b32 %1, %1, %0" : "+s"(s0), "+s"(s1) : : "scc"); // both write SCC
+		}
+	}
+	float s = 0;
+#pragma unroll
+	for (int i = 0; i < 4; i++)
+		s += v[i].x + v[i].y;
+	if (s == 123.456f || s0 == 0x12345u)
+		out[0] = s + s1;
+}
+
 template <typename K>
 int run(const char* name, K kernel, double ops_per_iter_per_lane, float* d_out)
 {
@@ -122,5 +160,12 @@ int main()
 	run("xorshift+add", bench<op_xorshift>, 1, d_out);
 	run("hash32", bench<op_hash32>, 1, d_out);
 	run("cmp+cndmask+add", bench<op_cndmask>, 1, d_out);
+	std::printf("-- 8 lane-FMAs per trip as 8 v_fma_f32 (plain) or 4 v_pk_fma_f32 (packed), plus 2*S scalar ALU instructions --\n");
+	run("plain  S=0", bench_mixed<0, false>, 1, d_out);
+	run("packed S=0", bench_mixed<0, true>, 1, d_out);
+	run("plain  S=2", bench_mixed<2, false>, 1, d_out);
+	run("packed S=2", bench_mixed<2, true>, 1, d_out);
+	run("plain  S=4", bench_mixed<4, false>, 1, d_out);
+	run("packed S=4", bench_mixed<4, true>, 1, d_out);
 	return 0;
 }
