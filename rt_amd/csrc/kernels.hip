@@ -3,26 +3,28 @@
 // What runs here is the whole of reference src/renderers/mg_ray_tracer.cpp:178-205 for one frame: the per-pixel
 // worker (:182-201), trace (:155-174), the closest-hit scans (:36-102) and the scatter functions (:110-140).
 //
-// Execution model (MI355X / CDNA4, 64-wide waves):
-//   * one lane owns one pixel and walks ALL of its samples; the per-pixel sum is therefore in sample order,
-//     exactly like the reference's `colour += trace(...)` loop (:187-194);
-//   * a wave covers an 8x8 pixel tile (lane = 8*row + column) so that its 64 rays stay coherent; a 256-thread
-//     workgroup is four such tiles side by side (32x8 pixels) — 8 rows = one stripe of the multi-GPU partition;
-//   * the (sample, bounce) double loop is FLATTENED: each loop trip advances every lane by one path segment; a
-//     lane whose path ended adds its sample and starts the next one in the same trip.  A wave therefore runs for
-//     max-over-lanes of the TOTAL segment count of a pixel (which concentrates around spp x mean path length),
-//     not for sum-over-samples of the max-over-lanes path length;
-//   * the closest-hit scan reads every primitive with a WAVE-UNIFORM address and skips a primitive's square
-//     root when no lane of the wave can hit it (one ballot);
-//   * three kernels, chosen by scene size:
+// Execution model (MI355X / CDNA4, 64-wide waves, 256-thread workgroups = 4 waves):
+//   * a lane traces one ray at a time; the unit of work is one CHUNK of 16 consecutive samples of one pixel (the
+//     arithmetic contract sums a pixel chunk-wise: each chunk in sample order, chunk sums in chunk order);
+//   * a wave owns a small pixel tile (2x2 ... 8x8) and works through a queue of its (pixel, chunk) items: a lane pulls
+//     the next item when it finishes one (ballot + mbcnt, no atomics), parks the chunk sum in a wave-private LDS slot,
+//     and at the end the pixels' slots are folded in chunk order and stored.  Short items keep all lanes busy and
+//     keep waves short, so that a launch has tens of thousands of waves to balance over the 1024 SIMDs;
+//   * the (sample, bounce) double loop is FLATTENED: each loop trip advances every lane by one path segment.  A trip is
+//     closest-hit query -> a miss ends the sample (sky) -> free lanes pull items -> ONE fused tail for "scatter a hit"
+//     and "start the next sample" (both consume random draws and end in the normalisation of a direction: issued
+//     once for the wave; only what really differs runs under its own lane mask);
+//   * the closest-hit scan reads every primitive with a WAVE-UNIFORM operand and skips a primitive's square-root half
+//     when no lane of the wave can hit it (ballots combined on the scalar unit);
+//   * one kernel template, three modes chosen by scene size:
 //       small    (<= 8 spheres, no planes: basic.toml, dielectric.toml): the spheres arrive as kernel arguments and
 //                live in SGPRs; the scan is fully unrolled straight-line code with scalar operands; only the
 //                per-lane lookups of the winning sphere go through LDS;
 //       resident (<= 1024 primitives): all primitives are staged ONCE per workgroup into LDS as float4s; the scan
-//                reads them as broadcast ds_read_b128 (no bank conflicts), software-prefetched one primitive ahead;
-//       tiled    (anything larger): primitives stream from the SoA columns in HBM through LDS in tiles of 1024
-//                (coalesced dword loads per column, radius squared on the way in); the workgroup moves in lock
-//                step, one path segment per trip, with barriers around each tile.
+//                reads them as broadcast ds_read_b128 (no bank conflicts), four spheres per group;
+//       tiled    (anything larger): primitives stream from the SoA columns in HBM/L2 through one LDS tile of 1024
+//                shared by the workgroup's waves (coalesced dword loads per column, radius squared on the way in);
+//                the workgroup moves in lock step, one path segment per trip, with barriers around each tile.
 // No MFMA: this is intersection arithmetic (subtract / dot / compare / sqrt), not a contraction.
 #include "kernels.hpp"
 #include "contract.hpp"
