@@ -26,8 +26,7 @@ $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC)
 
 # windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
-HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/renderer.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/null_renderer.cpp \
-                rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
+HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
 rt_amd/bin/rt_headless: $(HEADLESS_SRC) $(HOST_HDR) $(LIBDIR)/librt_hip.so
 	@mkdir -p rt_amd/bin
 	$(CXX) $(HOSTFLAGS) -o $@ $(HEADLESS_SRC) -L$(LIBDIR) -lrt_hip -Wl,-rpath,'$$ORIGIN/../lib'

@@ -28,6 +28,14 @@ using namespace std::string_view_literals;
 
 namespace
 {
+	// the do-nothing renderer of the reference (src/renderers/null_renderer.cpp): the minimal shape of a plug-in, and a
+	// second registry entry for --list / --renderer
+	struct null_renderer final : renderer_interface
+	{
+		void render(const rt::scene&, image_view&, muu::thread_pool&) noexcept override {}
+	};
+	REGISTER_RENDERER(null_renderer);
+
 	template <typename... Args>
 	void log(Args&&... args)
 	{

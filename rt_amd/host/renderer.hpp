@@ -2,14 +2,16 @@
 //
 // renderer_interface::render(const scene&, image_view&, thread_pool&) noexcept is THE drop-in boundary of the path
 // (reference src/renderer.hpp:9-14); REGISTER_RENDERER(T) installs {key, name, create} from a static initialiser
-// (:34-41) into a function-local registry with de-duplication by key (reference src/renderer.cpp:11-37).
+// (:34-41) into a function-local registry with de-duplication by key (reference src/renderer.cpp:11-69; header-only here).
 #pragma once
 
 #include "image.hpp"
 #include "scene.hpp"
 
+#include <algorithm>
 #include <span>
 #include <string_view>
+#include <vector>
 
 namespace muu
 {
@@ -47,10 +49,46 @@ namespace rt
 			create_func* create;
 		};
 
-		void install(const description& desc);
-		std::span<const description> all() noexcept;
-		const description* find_by_key(std::string_view) noexcept;
-		const description* find_by_name(std::string_view) noexcept;
+		namespace detail
+		{
+			// one registry per program; function-local so that static initialisers of other translation units can use it
+			inline std::vector<description>& registry() noexcept
+			{
+				static std::vector<description> entries;
+				return entries;
+			}
+
+			template <typename Match>
+			inline const description* first_match(Match&& match) noexcept
+			{
+				const auto& entries = registry();
+				const auto it = std::find_if(entries.begin(), entries.end(), match);
+				return it == entries.end() ? nullptr : &*it;
+			}
+		}
+
+		// a second registration under the same key replaces the first (reference src/renderer.cpp:21-37)
+		inline void install(const description& desc)
+		{
+			auto& entries = detail::registry();
+			const auto same_key = std::find_if(entries.begin(), entries.end(), [&](const description& d) { return d.key == desc.key; });
+			if (same_key != entries.end())
+				*same_key = desc;
+			else
+				entries.push_back(desc);
+		}
+
+		inline std::span<const description> all() noexcept { return detail::registry(); }
+
+		inline const description* find_by_key(std::string_view key) noexcept
+		{
+			return key.empty() ? nullptr : detail::first_match([&](const description& d) { return d.key == key; });
+		}
+
+		inline const description* find_by_name(std::string_view name) noexcept
+		{
+			return name.empty() ? nullptr : detail::first_match([&](const description& d) { return d.name == name; });
+		}
 	}
 }
 

@@ -1,4 +1,4 @@
-// rt_amd/host/scene.hpp — rt::scene as the renderer receives it, mirroring reference src/scene.hpp:8-25.
+// rt_amd/host/scene.hpp — what a renderer is handed: the scene description of reference src/scene.hpp:8-25.
 #pragma once
 
 #include "camera.hpp"
@@ -11,27 +11,31 @@ namespace rt
 {
 	struct scene
 	{
-		unsigned samples_per_pixel = 30; // reference src/scene.hpp:10
-		unsigned max_bounces = 10;		 // reference src/scene.hpp:11
+		// ---- how to sample (reference src/scene.hpp:10-11; the loader clamps both to [1, 1000]) ----
+		unsigned samples_per_pixel = 30;
+		unsigned max_bounces = 10;
 
-		std::string path;
+		// ---- what is in it ----
 		rt::camera camera;
 		rt::materials materials;
 		rt::planes planes;
 		rt::spheres spheres;
-		size_t box_count = 0; // boxes are parsed and validated but mg_ray_tracer never hits them (mg_ray_tracer.cpp:89-93)
+		size_t box_count = 0; // boxes are read and validated, but mg_ray_tracer never hits them (mg_ray_tracer.cpp:89-93)
 
-		// reference src/scene.cpp:483-618.  Throws std::runtime_error with the reference's messages.
+		// ---- where it came from ("" for parse() / synthetic()) ----
+		std::string path;
+
+		// Loaders; all throw std::runtime_error carrying the reference's messages.
+		//   load: a scene file, relative names searched like the reference does (src/scene.cpp:479-529); "-" = stdin
+		//   parse: TOML text already in memory
+		//   load_first_available: the first *.toml of the search directories (src/scene.cpp:620-643)
+		//   synthetic: SURVEY.md 8d "synthetic-100k" — a ground sphere plus (count - 1) small ones from splitmix64(20250310)
 		static scene load(std::string_view file);
-		// the same, from TOML text already in memory ("-" / stdin branch of the reference, src/scene.cpp:490-493)
 		static scene parse(std::string_view toml_text, std::string_view source_name = "<string>");
-		// reference src/scene.cpp:620-643
 		static scene load_first_available();
-
-		// SURVEY.md §8d "synthetic-100k": ground sphere + (count - 1) small spheres from splitmix64(seed 20250310)
 		static scene synthetic(unsigned sphere_count = 100000);
 	};
 
-	// named colour lookup with the reference's saturation quirk (src/colour.hpp:72-98): false if unknown
+	// named colour lookup with the reference's saturation quirk (src/colour.hpp:72-98); false if the name is unknown
 	bool named_colour(std::string_view name, colour& out) noexcept;
 }
