@@ -12,18 +12,18 @@ namespace rt
 	struct scene
 	{
 		// ---- how to sample (reference src/scene.hpp:10-11; the loader clamps both to [1, 1000]) ----
-		unsigned samples_per_pixel = 30;
-		unsigned max_bounces = 10;
+		unsigned samples_per_pixel{ 30u };
+		unsigned max_bounces{ 10u };
 
 		// ---- what is in it ----
-		rt::camera camera;
-		rt::materials materials;
-		rt::planes planes;
-		rt::spheres spheres;
+		rt::camera camera{};
+		rt::spheres spheres{};
+		rt::planes planes{};
+		rt::materials materials{};
 		size_t box_count = 0; // boxes are read and validated, but mg_ray_tracer never hits them (mg_ray_tracer.cpp:89-93)
 
 		// ---- where it came from ("" for parse() / synthetic()) ----
-		std::string path;
+		std::string path{};
 
 		// Loaders; all throw std::runtime_error carrying the reference's messages.
 		//   load: a scene file, relative names searched like the reference does (src/scene.cpp:479-529); "-" = stdin
