@@ -253,9 +253,11 @@ namespace rt_hip
 		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
 		// each tile, until all four queues are empty.
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
-		// launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs — the scans are latency-bound chains and want the waves
+		// launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs — the scans are latency-bound chains and want the waves.
+		// The tiled mode's LDS tile (16 KB + chunk slots per workgroup) admits 5 workgroups per CU anyway: it gets the
+		// registers of 5 waves per SIMD and needs no scratch.
 		template <int NS, bool SM>
-		__global__ __launch_bounds__(block_threads, 8) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : 8) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
