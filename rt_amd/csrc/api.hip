@@ -12,6 +12,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -298,7 +299,30 @@ namespace
 
 }
 
+namespace
+{
+	rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene);
+}
+
 extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
+{
+	try // nothing may propagate through the C boundary (the staging image below allocates)
+	{
+		return scene_upload(ctx, scene);
+	}
+	catch (const std::exception& e)
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_scene_upload: %s", e.what());
+	}
+	catch (...)
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_scene_upload: unknown exception");
+	}
+}
+
+namespace
+{
+rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
 {
 	if (!ctx || !scene)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_scene_upload: NULL argument");
@@ -449,6 +473,7 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 	ctx->have_scene = true;
 	ctx->stats.upload_ms = static_cast<float>(seconds_since(t0) * 1e3);
 	return ok();
+}
 }
 
 extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
