@@ -77,33 +77,60 @@ def assemble(gathered: torch.Tensor, width: int, height: int, stripe_rows: int, 
 
 
 class DistributedFrame:
-    """Per-rank state for rendering frames of one size across the ranks of a process group."""
+    """Per-rank state for rendering frames of one size across the ranks of a process group.
 
-    def __init__(self, tracer, width: int, height: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS, group=None):
-        self.tracer = tracer
+    `tracers`: one HipRayTracer per frame in flight, each with the scene already uploaded.  With two of them
+    consecutive frames alternate between two HIP streams (each with its own stripe buffer and context), so that the
+    tail of one frame's launch, its gather and its assemble overlap the start of the next frame's launch; every
+    frame is still complete and bit-identical — only throughput changes.  One tracer = strictly one frame at a time
+    on the caller's current stream."""
+
+    def __init__(self, tracers, width: int, height: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS, group=None):
+        self.tracers = list(tracers) if isinstance(tracers, (list, tuple)) else [tracers]
+        self.tracer = self.tracers[0]
         self.width, self.height, self.stripe_rows = width, height, stripe_rows
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.padded_rows = padded_rows(height, self.world, stripe_rows)
-        device = torch.device("cuda", tracer.device)
-        self.local = torch.zeros((self.padded_rows, width), dtype=torch.int32, device=device)
+        device = torch.device("cuda", self.tracer.device)
+        self.locals = [torch.zeros((self.padded_rows, width), dtype=torch.int32, device=device) for _ in self.tracers]
+        self.local = self.locals[0]
+        if len(self.tracers) > 1:
+            self.streams = [torch.cuda.Stream(device=device) for _ in self.tracers]
+            for stream in self.streams:
+                stream.wait_stream(torch.cuda.current_stream(device))  # the buffers above were zeroed on the current stream
+        else:
+            self.streams = [None]
+        self.frames = 0
 
     def render(self, seed: int = 1, flags: int = 0) -> torch.Tensor | None:
-        """Render this rank's stripes, gather, assemble.  Returns the int32[H, W] frame on rank 0, else None."""
-        stream = torch.cuda.current_stream().cuda_stream
-        self.tracer.render_device(
+        """Render this rank's stripes, gather, assemble.  Returns the int32[H, W] frame on rank 0, else None.
+        With several frames in flight the result is valid once its stream has been synchronised with
+        (torch.cuda.synchronize() does)."""
+        slot = self.frames % len(self.tracers)
+        self.frames += 1
+        if self.streams[slot] is None:
+            return self._render_on(slot, torch.cuda.current_stream(), seed, flags)
+        with torch.cuda.stream(self.streams[slot]):
+            return self._render_on(slot, self.streams[slot], seed, flags)
+
+    def _render_on(self, slot: int, stream, seed: int, flags: int) -> torch.Tensor | None:
+        tracer, local = self.tracers[slot], self.locals[slot]
+        tracer.render_device(
             self.width,
             self.height,
-            self.local.data_ptr(),
+            local.data_ptr(),
             seed=seed,
             flags=flags,
             partition=(self.rank, self.world, self.stripe_rows),
-            stream=stream,
+            stream=stream.cuda_stream,
         )
         if self.world == 1:
-            return self.local[: self.height]
-        gathered = gather_stripes(self.local, dst=0, group=self.group)
+            # one frame at a time: the stripe buffer IS the frame; with several in flight the buffer is reused two
+            # frames later, so the caller gets its own copy
+            return local[: self.height] if len(self.tracers) == 1 else local[: self.height].clone()
+        gathered = gather_stripes(local, dst=0, group=self.group)
         if gathered is None:
             return None
-        return assemble(gathered, self.width, self.height, self.stripe_rows, tracer=self.tracer, stream=stream)
+        return assemble(gathered, self.width, self.height, self.stripe_rows, tracer=tracer, stream=stream.cuda_stream)

@@ -14,7 +14,7 @@ from tests.conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, width, height, spp, seed, out_path):
+def _worker(rank, world, port, width, height, spp, seed, out_path, in_flight=1, frames=1):
     sys.path.insert(0, str(ROOT))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -27,19 +27,21 @@ def _worker(rank, world, port, width, height, spp, seed, out_path):
         from rt_amd import distributed
 
         torch.cuda.set_device(0)
-        tracer = rt_amd.HipRayTracer(device=0)
+        tracers = [rt_amd.HipRayTracer(device=0) for _ in range(in_flight)]
         scene = rt_amd.Scene.named("dielectric").set_sampling(spp)
-        tracer.upload(scene.describe(width, height))
-        frame = distributed.DistributedFrame(tracer, width, height)
+        for tracer in tracers:
+            tracer.upload(scene.describe(width, height))
+        frame = distributed.DistributedFrame(tracers, width, height)
         assert (frame.rank, frame.world) == (rank, world)
-        out = frame.render(seed=seed)
+        outs = [frame.render(seed=seed + k) for k in range(frames)]  # enqueued back to back, like bench.py's timed loop
         torch.cuda.synchronize()
         if rank == 0:
-            np.save(out_path, out.cpu().numpy().view(np.uint32))
+            np.save(out_path, np.stack([out.cpu().numpy().view(np.uint32) for out in outs]))
         else:
-            assert out is None
+            assert all(out is None for out in outs)
         dist.barrier()
-        tracer.close()
+        for tracer in tracers:
+            tracer.close()
     finally:
         dist.destroy_process_group()
 
@@ -57,4 +59,24 @@ def test_ranks_render_gather_and_assemble_the_oracle_frame(tmp_path, world):
     mp.spawn(_worker, args=(world, port, width, height, spp, seed, str(out_path)), nprocs=world, join=True)
     scene = rt_amd.Scene.named("dielectric").set_sampling(spp)
     want, _, _ = oracle.render(scene.describe(width, height), width, height, seed=seed, want_rgb=False)
-    assert np.array_equal(np.load(out_path), want)
+    assert np.array_equal(np.load(out_path)[0], want)
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_two_frames_in_flight_deliver_every_frame_intact(tmp_path, world):
+    """bench.py keeps two frames in flight on N > 1 (alternating streams, stripe buffers and contexts): five
+    consecutive frames with different seeds must each equal the oracle's frame."""
+    import rt_amd
+    from oracle import binding as oracle
+
+    width, height, spp, seed, frames = 96, 70, 8, 40, 5
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = tmp_path / "frames.npy"
+    mp.spawn(_worker, args=(world, port, width, height, spp, seed, str(out_path), 2, frames), nprocs=world, join=True)
+    got = np.load(out_path)
+    scene = rt_amd.Scene.named("dielectric").set_sampling(spp)
+    for k in range(frames):
+        want, _, _ = oracle.render(scene.describe(width, height), width, height, seed=seed + k, want_rgb=False)
+        assert np.array_equal(got[k], want), f"frame {k}"
