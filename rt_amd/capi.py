@@ -131,6 +131,7 @@ RT_HOST_SYMBOLS = [
     ("rt_host_scene_describe", C.c_int, [C.c_void_p, C.c_uint, C.c_uint, C.POINTER(RtHipScene)]),
     ("rt_host_screen_to_world", None, [C.c_void_p, C.c_uint, C.c_uint, C.c_float, C.c_float, C.c_float, C.c_float * 3]),
     ("rt_host_named_colour", C.c_int, [C.c_char_p, C.c_float * 4]),
+    ("rt_host_toml_to_json", C.c_long, [C.c_char_p, C.c_char_p, C.c_ulong]),
 ]
 
 

@@ -1,6 +1,11 @@
 // rt_amd/host/host_capi.cpp — see host_capi.h.
 #include "host_capi.h"
 #include "scene.hpp"
+#include "toml_subset.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
 
 #include <exception>
 #include <string>
@@ -129,4 +134,112 @@ extern "C" int rt_host_named_colour(const char* name, float out_rgba[4])
 		return 0;
 	out_rgba[0] = c.r, out_rgba[1] = c.g, out_rgba[2] = c.b, out_rgba[3] = c.a;
 	return 1;
+}
+
+namespace
+{
+	void json_string(std::string& out, const std::string& s)
+	{
+		out += '"';
+		for (const unsigned char c : s)
+		{
+			switch (c)
+			{
+				case '"': out += "\\\""; break;
+				case '\\': out += "\\\\"; break;
+				case '\n': out += "\\n"; break;
+				case '\r': out += "\\r"; break;
+				case '\t': out += "\\t"; break;
+				default:
+					if (c < 0x20)
+					{
+						char buf[8];
+						std::snprintf(buf, sizeof(buf), "\\u%04x", c);
+						out += buf;
+					}
+					else
+						out += static_cast<char>(c);
+			}
+		}
+		out += '"';
+	}
+
+	void json_node(std::string& out, const rt::toml::node& n)
+	{
+		using rt::toml::node_type;
+		switch (n.type)
+		{
+			case node_type::table:
+			{
+				out += '{';
+				bool first = true;
+				for (const auto& m : n.members)
+				{
+					if (!first)
+						out += ',';
+					first = false;
+					json_string(out, m.first);
+					out += ':';
+					json_node(out, m.second);
+				}
+				out += '}';
+				break;
+			}
+			case node_type::array:
+			{
+				out += '[';
+				for (size_t i = 0; i < n.elements.size(); i++)
+				{
+					if (i)
+						out += ',';
+					json_node(out, n.elements[i]);
+				}
+				out += ']';
+				break;
+			}
+			case node_type::string: json_string(out, n.string_value); break;
+			case node_type::integer: out += std::to_string(n.integer_value); break;
+			case node_type::floating_point:
+			{
+				if (std::isnan(n.float_value))
+					out += "\"nan\"";
+				else if (std::isinf(n.float_value))
+					out += n.float_value < 0 ? "\"-inf\"" : "\"inf\"";
+				else
+				{
+					char buf[40];
+					std::snprintf(buf, sizeof(buf), "%.17g", n.float_value);
+					out += buf;
+					if (!std::strpbrk(buf, ".eE"))
+						out += ".0"; // keep it a float for the reader on the other side
+				}
+				break;
+			}
+			case node_type::boolean: out += n.boolean_value ? "true" : "false"; break;
+			default: out += "null";
+		}
+	}
+}
+
+extern "C" long rt_host_toml_to_json(const char* toml_text, char* out, unsigned long capacity)
+{
+	try
+	{
+		g_error.clear();
+		const rt::toml::node root = rt::toml::parse(toml_text ? toml_text : "");
+		std::string json;
+		json_node(json, root);
+		if (out && capacity)
+		{
+			const size_t n = json.size() < capacity - 1 ? json.size() : capacity - 1;
+			std::memcpy(out, json.data(), n);
+			out[n] = '\0';
+		}
+		return static_cast<long>(json.size());
+	}
+	catch (const std::exception& e)
+	{
+		g_error = e.what();
+		return -1;
+	}
 }

@@ -34,6 +34,12 @@ int rt_host_scene_describe(const rt_host_scene* scene, unsigned width, unsigned 
 /* viewport::screen_to_world for tests */
 void rt_host_screen_to_world(const rt_host_scene* scene, unsigned width, unsigned height, float x, float y, float depth, float out[3]);
 
+/* The TOML reader on its own (tests cross-check it against an independent parser): parse `toml_text` and write the
+ * document as JSON into `out` (size `capacity`, always NUL-terminated).  Integers as JSON numbers, floats with 17
+ * significant digits (inf / nan as strings "inf", "-inf", "nan"), tables as objects in insertion order.
+ * Returns the number of bytes needed (excluding the NUL), or -1 on a parse error (see rt_host_last_error). */
+long rt_host_toml_to_json(const char* toml_text, char* out, unsigned long capacity);
+
 /* named colour lookup (1 = found) */
 int rt_host_named_colour(const char* name, float out_rgba[4]);
 

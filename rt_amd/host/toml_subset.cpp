@@ -285,12 +285,15 @@ namespace rt::toml
 				}
 				if (body.empty() || !(body[0] >= '0' && body[0] <= '9'))
 					fail("malformed value '" + std::string{ tok } + "'");
+				const auto is_digit_like = [](char c) noexcept
+				{ return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'f') || (c >= 'A' && c <= 'F'); };
 				std::string clean;
 				for (size_t i = 0; i < body.size(); i++)
 				{
 					if (body[i] == '_')
 					{
-						if (i == 0 || i + 1 == body.size() || body[i - 1] == '_')
+						// TOML 1.0: an underscore sits between two digits
+						if (i == 0 || i + 1 == body.size() || !is_digit_like(body[i - 1]) || !is_digit_like(body[i + 1]))
 							fail("misplaced '_' in number '" + std::string{ tok } + "'");
 						continue;
 					}
@@ -302,7 +305,37 @@ namespace rt::toml
 					base = clean[1] == 'x' ? 16 : (clean[1] == 'o' ? 8 : 2);
 					if (tok[0] == '+' || tok[0] == '-')
 						fail("prefixed integers may not have a sign");
+					if (body[2] == '_')
+						fail("misplaced '_' in number '" + std::string{ tok } + "'");
 					clean = clean.substr(2);
+				}
+				if (base == 10)
+				{
+					// TOML 1.0 decimal grammar: int = "0" | [1-9][0-9]*; frac = "." [0-9]+; exp = [eE] [+-]? [0-9]+
+					size_t i = 0;
+					const auto digits = [&]()
+					{
+						const size_t start = i;
+						while (i < clean.size() && clean[i] >= '0' && clean[i] <= '9')
+							i++;
+						return i - start;
+					};
+					const size_t int_digits = digits();
+					bool ok = int_digits > 0 && (int_digits == 1 || clean[0] != '0');
+					if (ok && i < clean.size() && clean[i] == '.')
+					{
+						i++;
+						ok = digits() > 0;
+					}
+					if (ok && i < clean.size() && (clean[i] == 'e' || clean[i] == 'E'))
+					{
+						i++;
+						if (i < clean.size() && (clean[i] == '+' || clean[i] == '-'))
+							i++;
+						ok = digits() > 0;
+					}
+					if (!ok || i != clean.size())
+						fail("malformed number '" + std::string{ tok } + "'");
 				}
 				const bool is_float = base == 10 && clean.find_first_of(".eE") != std::string::npos;
 				errno = 0;
@@ -367,7 +400,7 @@ namespace rt::toml
 				n.inline_table = true;
 				n.line = line_, n.column = col_;
 				advance(); // {
-				skip_blank(); // toml++ (TOML 1.1 preview) allows newlines in inline tables; accept them
+				skip_spaces(); // TOML 1.0 (what toml++ reads by default): an inline table stays on one line, no trailing comma
 				if (peek() == '}')
 				{
 					advance();
@@ -375,7 +408,7 @@ namespace rt::toml
 				}
 				while (true)
 				{
-					skip_blank();
+					skip_spaces();
 					const auto key = parse_key();
 					skip_spaces();
 					if (peek() != '=')
@@ -383,16 +416,10 @@ namespace rt::toml
 					advance();
 					skip_spaces();
 					insert(n, key, parse_value());
-					skip_blank();
+					skip_spaces();
 					if (peek() == ',')
 					{
 						advance();
-						skip_blank();
-						if (peek() == '}') // trailing comma
-						{
-							advance();
-							return n;
-						}
 						continue;
 					}
 					if (peek() == '}')
