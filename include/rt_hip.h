@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 1u
+#define RT_HIP_ABI_VERSION 2u
 
 typedef enum rt_hip_status
 {
@@ -98,6 +98,18 @@ typedef struct rt_hip_scene
 	 * Fixed order, independent of muu's storage order: element [r*4 + c] = m(r, c), so that
 	 * transform_position(v) = (M * (v.x, v.y, v.z, 1)).xyz / .w  with row r = sum_c m(r,c) * v_c. */
 	float inverse_view_projection[16];
+
+	/* rt::boxes — center_x..center_z/extents_x..extents_z/material columns (src/soa.toml:35-45); extents are half
+	 * sizes (muu::bounding_box).  mg_ray_tracer never hits boxes (mg_ray_tracer.cpp:89-93): only the preview
+	 * (RT_HIP_FLAG_PREVIEW, reference src/renderers/rasterizer.cpp:57) draws them. */
+	uint32_t n_boxes;
+	const float* box_center_x;
+	const float* box_center_y;
+	const float* box_center_z;
+	const float* box_extents_x;
+	const float* box_extents_y;
+	const float* box_extents_z;
+	const uint32_t* box_material;
 } rt_hip_scene;
 
 /*
@@ -135,7 +147,8 @@ enum
 	RT_HIP_KERNEL_NONE		= 0,
 	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup (<= 1024 primitives) */
 	RT_HIP_KERNEL_TILED		= 2, /* primitives streamed from the SoA columns through LDS in tiles (large scenes) */
-	RT_HIP_KERNEL_SMALL		= 3	 /* <= 8 spheres, no planes: scene in scalar registers, scan fully unrolled */
+	RT_HIP_KERNEL_SMALL		= 3, /* <= 8 spheres, no planes: scene in scalar registers, scan fully unrolled */
+	RT_HIP_KERNEL_PREVIEW	= 4	 /* RT_HIP_FLAG_PREVIEW: one primary ray per pixel, N.L shading */
 };
 
 /* Render flags.  0 = the parity contract: arithmetic bit-identical to oracle/ (see DESIGN.md §3). */
@@ -155,7 +168,13 @@ enum
 	 * mg_ray_tracer's: dielectric, air, vacuum, water and ice refract/reflect through dielectric_scatter (:181-219),
 	 * with the material's reflectivity as index of refraction.  Everything else is unchanged.  Opt-in: the parity
 	 * contract of this module is mg_ray_tracer, under which those materials are lambert. */
-	RT_HIP_FLAG_SM_MATERIALS = 1u << 3
+	RT_HIP_FLAG_SM_MATERIALS = 1u << 3,
+	/* draw the fast preview of reference src/renderers/rasterizer.cpp:24-85 instead of tracing paths (rt shows it at
+	 * low resolution while the camera moves, src/main.cpp:106,319): ONE ray through each pixel centre, closest hit
+	 * over planes, then boxes, then spheres, shaded 0.25 + 0.75 * albedo * (N . direction to the eye), the sky where
+	 * nothing is hit.  Deterministic: seed, samples_per_pixel and max_bounces are not read; d_rgb_f32 / rgb_f32
+	 * receive the colour before packing.  Partition, gather and assemble work as for the traced frame. */
+	RT_HIP_FLAG_PREVIEW = 1u << 4
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

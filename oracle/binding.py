@@ -17,6 +17,7 @@ ORACLE_DIR = Path(__file__).resolve().parent
 TRACE_ITERATIVE = 0
 TRACE_RECURSIVE = 1
 MATERIALS_SM = 2
+PREVIEW = 4
 
 
 class OracleStats(C.Structure):
@@ -63,6 +64,8 @@ def lib() -> C.CDLL:
         l.oracle_sky.argtypes = [C.c_float, C.c_void_p]
         l.oracle_primary_ray.restype = None
         l.oracle_primary_ray.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        l.oracle_hits_box.restype = C.c_int
+        l.oracle_hits_box.argtypes = [C.c_void_p] * 5
         l.oracle_dielectric_direction.restype = None
         l.oracle_dielectric_direction.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         _lib = l
@@ -73,14 +76,14 @@ def _local_rows(height, rank, world, stripe):
     return sum(1 for y in range(height) if (y // stripe) % world == rank)
 
 
-def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_order: int = TRACE_ITERATIVE, partition=None, want_rgb=True, threads: int = 0, sm_materials: bool = False):
-    """Counter-RNG strict-IEEE render.  Returns (rgba uint32[rows, W], rgb float32[rows, W, 3] | None, stats dict)."""
+def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_order: int = TRACE_ITERATIVE, partition=None, want_rgb=True, threads: int = 0, sm_materials: bool = False, preview: bool = False):
+    """Counter-RNG strict-IEEE render (preview=True: the one-ray-per-pixel preview of rasterizer.cpp instead).  Returns (rgba uint32[rows, W], rgb float32[rows, W, 3] | None, stats dict)."""
     rows = height if partition is None else _local_rows(height, *partition)
     rgba = np.zeros((rows, width), dtype=np.uint32)
     rgb = np.zeros((rows, width, 3), dtype=np.float32) if want_rgb else None
     stats = OracleStats()
     part = C.byref(RtHipPartition(*partition)) if partition is not None else None
-    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order | (MATERIALS_SM if sm_materials else 0), part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order | (MATERIALS_SM if sm_materials else 0) | (PREVIEW if preview else 0), part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed ({rc})")
     return rgba, rgb, stats.as_dict()
@@ -121,6 +124,14 @@ def sqrt_div(a, b):
     q = np.empty_like(a)
     lib().oracle_sqrt_div(a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data)
     return s, q
+
+
+def hits_box(origin, direction, center, extents):
+    """(hit, t) of the preview's ray-box test."""
+    arrays = [np.ascontiguousarray(v, dtype=np.float32) for v in (origin, direction, center, extents)]
+    t = np.zeros(1, dtype=np.float32)
+    hit = lib().oracle_hits_box(*(a.ctypes.data for a in arrays), t.ctypes.data)
+    return bool(hit), float(t[0])
 
 
 def pack(r: float, g: float, b: float) -> int:

@@ -239,6 +239,24 @@ namespace
 		return true;
 	}
 
+	// Axis-aligned box, slab method (muu::ray::hits(bounding_box): restated; corners = center -/+ extents).  Only the
+	// preview draws boxes.  Contract: reciprocal direction by IEEE division, compare-and-select minima / maxima (a NaN
+	// from 0 * inf that survives them makes `tmax >= tmin` false = miss), origin inside -> the exit distance.
+	inline float select_min(float a, float b) { return a < b ? a : b; }
+	inline float select_max(float a, float b) { return a > b ? a : b; }
+	inline bool hits_box(const ray& r, vec3 lo, vec3 hi, float& t)
+	{
+		const vec3 inv = { 1.0f / r.dir.x, 1.0f / r.dir.y, 1.0f / r.dir.z };
+		const vec3 t1 = { (lo.x - r.origin.x) * inv.x, (lo.y - r.origin.y) * inv.y, (lo.z - r.origin.z) * inv.z };
+		const vec3 t2 = { (hi.x - r.origin.x) * inv.x, (hi.y - r.origin.y) * inv.y, (hi.z - r.origin.z) * inv.z };
+		const float tmin = select_max(select_max(select_min(t1.x, t2.x), select_min(t1.y, t2.y)), select_min(t1.z, t2.z));
+		const float tmax = select_min(select_min(select_max(t1.x, t2.x), select_max(t1.y, t2.y)), select_max(t1.z, t2.z));
+		if (!(tmax >= tmin) || tmax < 0.0f)
+			return false;
+		t = tmin >= 0.0f ? tmin : tmax;
+		return true;
+	}
+
 	struct hit_result // mg_ray_tracer.cpp:22-33
 	{
 		float distance;
@@ -526,6 +544,70 @@ namespace
 		colour = { std::sqrt(colour.x), std::sqrt(colour.y), std::sqrt(colour.z) }; // :196-198
 		out_rgba = pack(colour);													 // :200
 	}
+
+	// ---- the preview: worker lambda of src/renderers/rasterizer.cpp:28-82 for the pixel at (x, y) ------------------
+	// One ray through the pixel centre; a candidate replaces the current hit only if strictly nearer (:48), in the
+	// order planes, boxes, spheres (:62-64); no minimum distance.  A box hit leaves the normal as it was (:56-59).
+	inline void preview_pixel(const frame& f, uint32_t x, uint32_t y, uint32_t& out_rgba, float* out_rgb)
+	{
+		const rt_hip_scene& s = *f.scene;
+		const float px = static_cast<float>(x) + 0.5f, py = static_cast<float>(y) + 0.5f;
+		const vec3 near_pos = screen_to_world(f, px, py, 0.0f); // :30
+		const vec3 far_pos = screen_to_world(f, px, py, 1.0f);	// :31
+		const vec3 delta = far_pos - near_pos;
+		float dist = std::sqrt(dot(delta, delta)) + 1.0f; // max_dist + 1 (:33,35)
+		const ray r = { near_pos, normalize(delta) };	  // :39
+		bool hit = false;
+		uint32_t material = 0;
+		vec3 hit_pos = { 0, 0, 0 };
+		vec3 normal = { 0, 1, 0 }; // vec3::constants::up (:38)
+		for (uint32_t i = 0; i < s.n_planes; i++)
+		{
+			const vec3 n = { s.plane_normal_x[i], s.plane_normal_y[i], s.plane_normal_z[i] };
+			float t;
+			if (hits_plane(r, n, s.plane_d[i], t) && t < dist)
+				dist = t, hit = true, material = s.plane_material[i], hit_pos = r.at(t), normal = n;
+		}
+		for (uint32_t i = 0; i < s.n_boxes; i++)
+		{
+			const vec3 c = { s.box_center_x[i], s.box_center_y[i], s.box_center_z[i] };
+			const vec3 e = { s.box_extents_x[i], s.box_extents_y[i], s.box_extents_z[i] };
+			float t;
+			if (hits_box(r, c - e, c + e, t) && t < dist)
+				dist = t, hit = true, material = s.box_material[i], hit_pos = r.at(t);
+		}
+		for (uint32_t i = 0; i < s.n_spheres; i++)
+		{
+			const vec3 c = { s.sphere_center_x[i], s.sphere_center_y[i], s.sphere_center_z[i] };
+			float t;
+			if (hits_sphere(r, c, s.sphere_radius[i], t) && t < dist)
+			{
+				dist = t, hit = true, material = s.sphere_material[i], hit_pos = r.at(t);
+				normal = direction(c, hit_pos); // :54
+			}
+		}
+		vec3 colour;
+		if (hit)
+		{
+			// min(0.25 + lambert(N, direction(hit, near), albedo) * 0.75, 1) (:66-73); lambert = (L . N) * albedo * 1 (:13-20)
+			const float* albedo = s.material_albedo + material * 4;
+			const float k = dot(direction(hit_pos, near_pos), normal);
+			const vec3 v = { (k * albedo[0]) * 0.75f + 0.25f, (k * albedo[1]) * 0.75f + 0.25f, (k * albedo[2]) * 0.75f + 0.25f };
+			colour = { select_min(v.x, 1.0f), select_min(v.y, 1.0f), select_min(v.z, 1.0f) };
+		}
+		else
+		{
+			// lerp(sky_start, sky_end, y / (H - 1)) (:76-80) with sky_start = colour{208, 228, 255} and sky_end =
+			// colour{238, 245, 255} (:66-67): the integer constructor clamps each channel to [0, 1] (colour.hpp:72-91), so
+			// both are white.  A one-row frame divides 0 by 0: NaN, which packs to black.
+			const float t = static_cast<float>(y) / static_cast<float>(f.height - 1u);
+			const float c = std::fmaf(1.0f - 1.0f, t, 1.0f);
+			colour = { c, c, c };
+		}
+		if (out_rgb)
+			out_rgb[0] = colour.x, out_rgb[1] = colour.y, out_rgb[2] = colour.z;
+		out_rgba = pack(colour);
+	}
 }
 
 extern "C" int oracle_render(const rt_hip_scene* scene,
@@ -572,7 +654,13 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 			for (uint32_t x = 0; x < width; x++)
 			{
 				const size_t o = local_y * width + x;
-				render_pixel(f, x, y, rgba8[o], rgb_f32 ? rgb_f32 + o * 3 : nullptr, c);
+				if (mode & ORACLE_PREVIEW)
+				{
+					preview_pixel(f, x, y, rgba8[o], rgb_f32 ? rgb_f32 + o * 3 : nullptr);
+					c.segments++;
+				}
+				else
+					render_pixel(f, x, y, rgba8[o], rgb_f32 ? rgb_f32 + o * 3 : nullptr, c);
 			}
 		}
 		segments += c.segments;
@@ -587,7 +675,7 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 
 	if (stats)
 	{
-		stats->primary_samples = static_cast<uint64_t>(rows.size()) * width * scene->samples_per_pixel;
+		stats->primary_samples = static_cast<uint64_t>(rows.size()) * width * ((mode & ORACLE_PREVIEW) ? 1u : scene->samples_per_pixel);
 		stats->segments = segments.load();
 		stats->sphere_tests = stats->segments * scene->n_spheres;
 		stats->plane_tests = stats->segments * scene->n_planes;
@@ -666,4 +754,14 @@ extern "C" void oracle_dielectric_direction(const float* dir, const float* norma
 	out_dir[0] = r.x;
 	out_dir[1] = r.y;
 	out_dir[2] = r.z;
+}
+
+extern "C" int oracle_hits_box(const float* origin, const float* dir, const float* center, const float* extents, float* out_t)
+{
+	const ray r = { { origin[0], origin[1], origin[2] }, { dir[0], dir[1], dir[2] } };
+	const vec3 c = { center[0], center[1], center[2] }, e = { extents[0], extents[1], extents[2] };
+	float t = 0.0f;
+	const bool hit = hits_box(r, c - e, c + e, t);
+	*out_t = hit ? t : -1.0f;
+	return hit ? 1 : 0;
 }

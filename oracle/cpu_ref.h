@@ -36,7 +36,8 @@ enum
 {
 	ORACLE_TRACE_ITERATIVE = 0, /* the arithmetic contract shared with the GPU (forward throughput product) */
 	ORACLE_TRACE_RECURSIVE = 1, /* literal recursion of mg_ray_tracer.cpp:155-174 (attenuation * trace(...)) */
-	ORACLE_MATERIALS_SM	   = 2	/* scatter table of sm_ray_tracer.cpp:221-236: dielectric/air/vacuum/water/ice refract */
+	ORACLE_MATERIALS_SM	   = 2, /* scatter table of sm_ray_tracer.cpp:221-236: dielectric/air/vacuum/water/ice refract */
+	ORACLE_PREVIEW		   = 4	/* src/renderers/rasterizer.cpp:24-85 instead of mg_ray_tracer: one ray per pixel (seed unused) */
 };
 
 /* Counter-RNG, strict IEEE render: the parity oracle.  rgba8 / rgb_f32 are local_rows x width (compact
@@ -81,6 +82,8 @@ uint32_t oracle_pack(float r, float g, float b);			   /* rt::colour{vec3} -> uin
 void oracle_sky(float dir_y, float* out_rgb);				   /* mg_ray_tracer.cpp:164 */
 /* sm_ray_tracer.cpp:181-219: direction chosen by dielectric_scatter for the uniform number u; also the reflect probability */
 void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob);
+/* ray vs axis-aligned box (center, half extents): 1 = hit and *out_t set.  The slab test of the preview. */
+int oracle_hits_box(const float* origin, const float* dir, const float* center, const float* extents, float* out_t);
 void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir);
 
 #ifdef __cplusplus

@@ -16,13 +16,14 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 
-RT_HIP_ABI_VERSION = 1
+RT_HIP_ABI_VERSION = 2
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
 RT_HIP_FLAG_PERSISTENT_FRAME = 1 << 2
 RT_HIP_FLAG_SM_MATERIALS = 1 << 3
-KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small"}
+RT_HIP_FLAG_PREVIEW = 1 << 4
+KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview"}
 
 STATUS_NAMES = {
     0: "RT_HIP_OK",
@@ -67,6 +68,14 @@ class RtHipScene(C.Structure):
         ("samples_per_pixel", C.c_uint32),
         ("max_bounces", C.c_uint32),
         ("inverse_view_projection", C.c_float * 16),
+        ("n_boxes", C.c_uint32),
+        ("box_center_x", c_float_p),
+        ("box_center_y", c_float_p),
+        ("box_center_z", c_float_p),
+        ("box_extents_x", c_float_p),
+        ("box_extents_y", c_float_p),
+        ("box_extents_z", c_float_p),
+        ("box_material", c_u32_p),
     ]
 
 

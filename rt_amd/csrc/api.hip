@@ -262,7 +262,7 @@ namespace
 			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u spheres but a sphere column is NULL", s.n_spheres);
 		if (s.n_planes && (!s.plane_normal_x || !s.plane_normal_y || !s.plane_normal_z || !s.plane_d || !s.plane_material))
 			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u planes but a plane column is NULL", s.n_planes);
-		if (!s.n_materials && (s.n_spheres || s.n_planes))
+		if (!s.n_materials && (s.n_spheres || s.n_planes || s.n_boxes))
 			return fail(RT_HIP_INVALID_ARGUMENT, "scene: primitives present but no materials");
 		if (s.n_materials && (!s.material_type || !s.material_albedo || !s.material_roughness || !s.material_reflectivity))
 			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u materials but a material column is NULL", s.n_materials);
@@ -274,6 +274,11 @@ namespace
 		for (uint32_t i = 0; i < s.n_planes; i++)
 			if (s.plane_material[i] >= s.n_materials)
 				return fail(RT_HIP_INVALID_ARGUMENT, "scene: plane %u has material index %u out-of-range", i, s.plane_material[i]);
+		if (s.n_boxes && (!s.box_center_x || !s.box_center_y || !s.box_center_z || !s.box_extents_x || !s.box_extents_y || !s.box_extents_z || !s.box_material))
+			return fail(RT_HIP_INVALID_ARGUMENT, "scene: %u boxes but a box column is NULL", s.n_boxes);
+		for (uint32_t i = 0; i < s.n_boxes; i++)
+			if (s.box_material[i] >= s.n_materials)
+				return fail(RT_HIP_INVALID_ARGUMENT, "scene: box %u has material index %u out-of-range", i, s.box_material[i]);
 		return ok();
 	}
 
@@ -353,6 +358,8 @@ rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
 	const size_t o_prim_metal = place(n_primitives * 4);
 	const size_t o_prim_shading_sm = place(n_primitives * sizeof(float4));
 	const size_t o_prim_scatter_sm = place(n_primitives * 4);
+	const size_t o_box_bounds = place(static_cast<size_t>(s.n_boxes) * 2 * sizeof(float4));
+	const size_t o_albedo = place(static_cast<size_t>(s.n_materials) * sizeof(float4));
 	const size_t total = offset ? offset : column_alignment;
 
 	// host image of the block (one H2D copy)
@@ -383,6 +390,15 @@ rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
 		put(o_shading + m * sizeof(float4), shading, sizeof(shading));
 	}
 	put(o_type, s.material_type, static_cast<size_t>(s.n_materials) * 4);
+	put(o_albedo, s.material_albedo, static_cast<size_t>(s.n_materials) * sizeof(float4));
+	for (uint32_t i = 0; i < s.n_boxes; i++)
+	{
+		// corners = center -/+ extents (muu::bounding_box), material index riding in the spare lane
+		float bounds[8] = { s.box_center_x[i] - s.box_extents_x[i], s.box_center_y[i] - s.box_extents_y[i], s.box_center_z[i] - s.box_extents_z[i], 0.0f,
+							s.box_center_x[i] + s.box_extents_x[i], s.box_center_y[i] + s.box_extents_y[i], s.box_center_z[i] + s.box_extents_z[i], 0.0f };
+		std::memcpy(&bounds[3], &s.box_material[i], 4);
+		put(o_box_bounds + i * 2 * sizeof(float4), bounds, sizeof(bounds));
+	}
 	// derived per-primitive tables (spheres, then planes)
 	ctx->small = small_scene{};
 	ctx->small_sm = small_scene{};
@@ -466,6 +482,9 @@ rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
 	d.primitive_scatter = reinterpret_cast<const uint32_t*>(base + o_prim_metal);
 	d.primitive_shading_sm = reinterpret_cast<const float4*>(base + o_prim_shading_sm);
 	d.primitive_scatter_sm = reinterpret_cast<const uint32_t*>(base + o_prim_scatter_sm);
+	d.n_boxes = s.n_boxes;
+	d.box_bounds = reinterpret_cast<const float4*>(base + o_box_bounds);
+	d.material_albedo = reinterpret_cast<const float4*>(base + o_albedo);
 
 	ctx->samples_per_pixel = s.samples_per_pixel;
 	ctx->max_bounces = s.max_bounces;
@@ -492,7 +511,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
 	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
-	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS))
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
 	if (!ctx->have_scene)
 		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
@@ -534,13 +553,17 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 
 	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
 	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
-	const uint32_t variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	uint32_t variant = RT_HIP_KERNEL_PREVIEW;
+	if (flags & RT_HIP_FLAG_PREVIEW)
+		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	else
+		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
 	ctx->render_recorded = true;
 	ctx->last_stream = s;
 	ctx->stats.kernel_variant = variant;
-	ctx->stats.primary_samples = static_cast<uint64_t>(f.local_rows) * width * f.samples_per_pixel;
+	ctx->stats.primary_samples = static_cast<uint64_t>(f.local_rows) * width * ((flags & RT_HIP_FLAG_PREVIEW) ? 1u : f.samples_per_pixel);
 	return ok();
 }
 

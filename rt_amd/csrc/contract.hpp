@@ -228,6 +228,25 @@ namespace rt_hip
 		return true;
 	}
 
+	// Axis-aligned box given by its min and max corners (muu::bounding_box = center -/+ extents), slab method.  Drawn by
+	// the preview only.  Selections are written as compare-and-select so that NaN (0 * inf: a ray parallel to a slab and
+	// starting exactly on it) and signed zeros behave the same here and in the oracle; a NaN that survives makes
+	// `tmax >= tmin` false = miss.  Origin inside the box: the exit distance, like hits_sphere's far root.
+	__device__ __forceinline__ float select_min(float a, float b) { return a < b ? a : b; }
+	__device__ __forceinline__ float select_max(float a, float b) { return a > b ? a : b; }
+	__device__ __forceinline__ bool hits_box(vec3 o, vec3 d, vec3 lo, vec3 hi, float& t)
+	{
+		const vec3 inv = { rcp_rn(d.x), rcp_rn(d.y), rcp_rn(d.z) };
+		const vec3 t1 = (lo - o) * inv;
+		const vec3 t2 = (hi - o) * inv;
+		const float tmin = select_max(select_max(select_min(t1.x, t2.x), select_min(t1.y, t2.y)), select_min(t1.z, t2.z));
+		const float tmax = select_min(select_min(select_max(t1.x, t2.x), select_max(t1.y, t2.y)), select_max(t1.z, t2.z));
+		if (!(tmax >= tmin) || tmax < 0.0f)
+			return false;
+		t = tmin >= 0.0f ? tmin : tmax;
+		return true;
+	}
+
 	// ---- shading --------------------------------------------------------------------------------------------
 	// mg_ray_tracer.cpp:164
 	__device__ __forceinline__ vec3 sky(float dir_y)

@@ -623,6 +623,108 @@ namespace rt_hip
 			add_segments(counters, st.segments);
 		}
 
+		// ---- preview: reference src/renderers/rasterizer.cpp:24-85 ----------------------------------------------------
+		// One thread per pixel, one ray through the pixel centre; every lane of a wave walks the same primitive, so the
+		// reads below are wave-uniform (scalar loads through the constant cache / L2).  4 bytes written per pixel and a
+		// few dozen flops per primitive: a frame of a small scene is bound by the store and the launch, nothing to tune.
+		__global__ __launch_bounds__(block_threads) void preview_frame(const frame_params p,
+																	   const device_scene s,
+																	   uint32_t* __restrict__ out_rgba,
+																	   float* __restrict__ out_rgb,
+																	   device_counters* __restrict__ counters)
+		{
+			const uint32_t lx = blockIdx.x * 64u + (threadIdx.x & 63u);
+			const uint32_t ly = blockIdx.y * (block_threads / 64u) + (threadIdx.x >> 6);
+			const bool alive = lx < p.width && ly < p.local_rows;
+			const uint32_t gy = global_row(alive ? ly : 0u, p);
+
+			// :30-32 — near and far points of the pixel centre
+			const float ndc_x = fma(static_cast<float>(lx) + 0.5f, p.sx, -1.0f);
+			const float ndc_y = fma(static_cast<float>(gy) + 0.5f, p.neg_sy, 1.0f);
+			float near_row[4], far_row[4];
+#pragma unroll
+			for (int r = 0; r < 4; r++)
+			{
+				near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
+				far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
+			}
+			const float inv_wn = rcp_rn(near_row[3]), inv_wf = rcp_rn(far_row[3]);
+			const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
+			const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
+			const vec3 delta = far_pos - near_pos;
+			const vec3 dir = normalize(delta);					// vec3::direction(near, far) (:39)
+			float dist = sqrt_rn(dot(delta, delta)) + 1.0f;		// max_dist + 1 (:33,35)
+			bool hit = false;
+			uint32_t material = 0;
+			vec3 hit_pos = { 0.0f, 0.0f, 0.0f };
+			vec3 normal = { 0.0f, 1.0f, 0.0f };					// vec3::constants::up (:38)
+
+			// hit_tests (:41-61): a candidate replaces the current one only if strictly nearer; planes, boxes, spheres
+			for (uint32_t i = 0; i < s.n_planes; i++)
+			{
+				const float4 g = s.primitive_geometry[s.n_spheres + i];
+				float t;
+				if (hits_plane(near_pos, dir, { g.x, g.y, g.z }, g.w, t) && t < dist)
+				{
+					dist = t, hit = true, material = s.plane_material[i];
+					hit_pos = ray_at(near_pos, dir, t);
+					normal = { g.x, g.y, g.z };
+				}
+			}
+			for (uint32_t i = 0; i < s.n_boxes; i++)
+			{
+				const float4 lo = s.box_bounds[2u * i], hi = s.box_bounds[2u * i + 1u];
+				float t;
+				if (hits_box(near_pos, dir, { lo.x, lo.y, lo.z }, { hi.x, hi.y, hi.z }, t) && t < dist)
+				{
+					dist = t, hit = true, material = __float_as_uint(lo.w);
+					hit_pos = ray_at(near_pos, dir, t); // the normal stays what it was: the reference sets none for a box (:56-59)
+				}
+			}
+			for (uint32_t i = 0; i < s.n_spheres; i++)
+			{
+				const float4 g = s.primitive_geometry[i];
+				float t;
+				if (hits_sphere(near_pos, dir, { g.x, g.y, g.z }, g.w, t) && t < dist)
+				{
+					dist = t, hit = true, material = s.sphere_material[i];
+					hit_pos = ray_at(near_pos, dir, t);
+					normal = normalize(hit_pos - vec3{ g.x, g.y, g.z });
+				}
+			}
+
+			vec3 colour;
+			if (hit)
+			{
+				// min(0.25 + lambert(N, direction to the eye, albedo) * 0.75, 1) (:66-73); lambert = (L . N) * albedo (:13-20)
+				const float4 albedo = s.material_albedo[material];
+				const float k = dot(normalize(near_pos - hit_pos), normal);
+				const vec3 v = { (k * albedo.x) * 0.75f + 0.25f, (k * albedo.y) * 0.75f + 0.25f, (k * albedo.z) * 0.75f + 0.25f };
+				colour = { select_min(v.x, 1.0f), select_min(v.y, 1.0f), select_min(v.z, 1.0f) };
+			}
+			else
+			{
+				// lerp(sky_start, sky_end, y / (H - 1)) (:76-80).  Both sky colours are built from integers through
+				// colour's clamping constructor (colour.hpp:72-91), which turns every non-zero byte into 1.0: the sky is
+				// white, and NaN for a one-row frame (0 / 0), which packs to black.
+				const float t = static_cast<float>(gy) / static_cast<float>(p.height - 1u);
+				const float c = fma(1.0f - 1.0f, t, 1.0f);
+				colour = { c, c, c };
+			}
+			if (alive)
+			{
+				const size_t o = static_cast<size_t>(ly) * p.width + lx;
+				if (out_rgb)
+				{
+					out_rgb[o * 3 + 0] = colour.x;
+					out_rgb[o * 3 + 1] = colour.y;
+					out_rgb[o * 3 + 2] = colour.z;
+				}
+				out_rgba[o] = pack_rgba8888(colour);
+			}
+			add_segments(counters, alive ? 1u : 0u);
+		}
+
 		// ---- multi-GPU assemble: rank-major compact stripes -> frame ------------------------------------------------
 		__global__ __launch_bounds__(block_threads) void assemble_stripes(uint32_t width,
 																		  uint32_t height,
@@ -864,6 +966,15 @@ namespace rt_hip
 		}
 		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 		return variant;
+	}
+
+	void launch_preview(const frame_params& frame, const device_scene& scene, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream)
+	{
+		if (!frame.width || !frame.local_rows)
+			return;
+		const uint32_t rows_per_block = block_threads / 64u;
+		const dim3 grid((frame.width + 63u) / 64u, (frame.local_rows + rows_per_block - 1u) / rows_per_block);
+		hipLaunchKernelGGL(preview_frame, grid, dim3(block_threads), 0, stream, frame, scene, d_rgba8, d_rgb_f32, d_counters);
 	}
 
 	void launch_assemble(uint32_t width,

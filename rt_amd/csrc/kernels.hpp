@@ -36,6 +36,11 @@ namespace rt_hip
 		// and ice become scatter_dielectric, and their shading.w carries the reflectivity (= index of refraction)
 		const float4* primitive_shading_sm;
 		const uint32_t* primitive_scatter_sm;
+		// what only the preview reads (RT_HIP_FLAG_PREVIEW): the boxes as two float4 each — (min corner, material index
+		// as bits) and (max corner, 0), corners = center -/+ extents — and the materials' plain albedo
+		uint32_t n_boxes;
+		const float4* box_bounds;
+		const float4* material_albedo;
 	};
 
 	enum : uint32_t
@@ -106,6 +111,9 @@ namespace rt_hip
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
 						   hipStream_t stream);
+
+	// RT_HIP_FLAG_PREVIEW: one ray per pixel, reference src/renderers/rasterizer.cpp:24-85
+	void launch_preview(const frame_params& frame, const device_scene& scene, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream);
 
 	void launch_assemble(uint32_t width,
 						 uint32_t height,

@@ -23,8 +23,9 @@ using namespace rt;
 
 namespace
 {
-	// SmMaterials = false: mg_ray_tracer's scatter table; true: sm_ray_tracer's (dielectrics refract), see RT_HIP_FLAG_SM_MATERIALS
-	template <bool SmMaterials>
+	// ModeFlags: 0 = mg_ray_tracer's scatter table; RT_HIP_FLAG_SM_MATERIALS = sm_ray_tracer's (dielectrics refract);
+	// RT_HIP_FLAG_PREVIEW = the one-ray-per-pixel preview of src/renderers/rasterizer.cpp
+	template <uint32_t ModeFlags>
 	struct hip_renderer : renderer_interface
 	{
 		rt_hip_ctx* ctx = nullptr;
@@ -66,6 +67,14 @@ namespace
 			s.material_albedo = reinterpret_cast<const float*>(scene.materials.albedo());
 			s.material_roughness = scene.materials.roughness();
 			s.material_reflectivity = scene.materials.reflectivity();
+			s.n_boxes = static_cast<uint32_t>(scene.boxes.size());
+			s.box_center_x = scene.boxes.center_x();
+			s.box_center_y = scene.boxes.center_y();
+			s.box_center_z = scene.boxes.center_z();
+			s.box_extents_x = scene.boxes.extents_x();
+			s.box_extents_y = scene.boxes.extents_y();
+			s.box_extents_z = scene.boxes.extents_z();
+			s.box_material = scene.boxes.material();
 			s.samples_per_pixel = scene.samples_per_pixel;
 			s.max_bounces = scene.max_bounces;
 			const auto view = scene.camera.viewport(pixels.size()); // mg_ray_tracer.cpp:180
@@ -78,16 +87,19 @@ namespace
 			const char* fixed = std::getenv("RT_HIP_SEED");
 			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
 
-			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME) | (SmMaterials ? static_cast<uint32_t>(RT_HIP_FLAG_SM_MATERIALS) : 0u), nullptr, nullptr) != RT_HIP_OK)
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME) | ModeFlags, nullptr, nullptr) != RT_HIP_OK)
 				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
 		}
 	};
 
-	struct hip_ray_tracer final : hip_renderer<false>
+	struct hip_ray_tracer final : hip_renderer<RT_HIP_FLAG_NONE>
 	{};
-	struct hip_sm_ray_tracer final : hip_renderer<true>
+	struct hip_sm_ray_tracer final : hip_renderer<RT_HIP_FLAG_SM_MATERIALS>
+	{};
+	struct hip_rasterizer final : hip_renderer<RT_HIP_FLAG_PREVIEW>
 	{};
 
 	REGISTER_RENDERER(hip_ray_tracer);
 	REGISTER_RENDERER(hip_sm_ray_tracer);
+	REGISTER_RENDERER(hip_rasterizer);
 }

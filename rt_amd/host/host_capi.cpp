@@ -111,6 +111,14 @@ extern "C" int rt_host_scene_describe(const rt_host_scene* scene, unsigned width
 	out->material_albedo = reinterpret_cast<const float*>(s.materials.albedo());
 	out->material_roughness = s.materials.roughness();
 	out->material_reflectivity = s.materials.reflectivity();
+	out->n_boxes = static_cast<uint32_t>(s.boxes.size());
+	out->box_center_x = s.boxes.center_x();
+	out->box_center_y = s.boxes.center_y();
+	out->box_center_z = s.boxes.center_z();
+	out->box_extents_x = s.boxes.extents_x();
+	out->box_extents_y = s.boxes.extents_y();
+	out->box_extents_z = s.boxes.extents_z();
+	out->box_material = s.boxes.material();
 	out->samples_per_pixel = s.samples_per_pixel;
 	out->max_bounces = s.max_bounces;
 	const rt::viewport view = s.camera.viewport({ width, height });

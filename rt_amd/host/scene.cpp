@@ -7,7 +7,7 @@
 //                                                                               src/scene.cpp:540-566
 //   planes[] = { position (0,0,0), normal (0,1,0) normalised, material }        src/scene.cpp:576-585
 //   spheres[] = { position (0,1,-3), radius 0.5, material }                     src/scene.cpp:587-597
-//   boxes[] = { position, extents, material } (validated, not rendered by mg)   src/scene.cpp:599-615
+//   boxes[] = { position, extents, material } (not hit by mg; drawn by the preview)   src/scene.cpp:599-615
 //   vectors: alias string | one number (broadcast) | array of <= N numbers      src/scene.cpp:118-167
 //   colours: named alias (saturating, src/colour.hpp:72-98) | array of <= 4     src/scene.cpp:187-357
 //   enums: integer value or enumerator name                                     src/scene.cpp:383-405
@@ -283,10 +283,8 @@ namespace rt
 			{
 				for (const auto& tbl : boxes->elements)
 				{
-					(void)deserialize(tbl, "position", vec3{ 0, 1, -3 });
-					(void)deserialize(tbl, "extents", vec3{ 0.5f, 0.5f, 0.5f });
-					(void)get_material(tbl);
-					s.box_count++;
+					const auto value = rt::box{ deserialize(tbl, "position", vec3{ 0, 1, -3 }), deserialize(tbl, "extents", vec3{ 0.5f, 0.5f, 0.5f }) };
+					s.boxes.push_back(value, get_material(tbl), value.center.x, value.center.y, value.center.z, value.extents.x, value.extents.y, value.extents.z);
 				}
 			}
 			return s;

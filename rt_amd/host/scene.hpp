@@ -20,7 +20,7 @@ namespace rt
 		rt::spheres spheres{};
 		rt::planes planes{};
 		rt::materials materials{};
-		size_t box_count = 0; // boxes are read and validated, but mg_ray_tracer never hits them (mg_ray_tracer.cpp:89-93)
+		rt::boxes boxes{}; // loaded like the rest; mg_ray_tracer never hits them (mg_ray_tracer.cpp:89-93), the preview draws them
 
 		// ---- where it came from ("" for parse() / synthetic()) ----
 		std::string path{};

@@ -1,6 +1,6 @@
 // rt_amd/host/soa.hpp — struct-of-arrays tables with the column names of the reference's soagen tables.
 //
-// Mirrors the subset of rt::materials / rt::planes / rt::spheres the path reads (reference src/soa.toml:6-33;
+// Mirrors rt::materials / rt::planes / rt::spheres / rt::boxes as the path reads them (reference src/soa.toml:6-45;
 // generated accessors src/soa.hpp:177-199): named column accessors returning raw pointers, size(), push_back
 // with one argument per column in declaration order (as used at reference src/scene.cpp:558-562,583,594-595).
 // Float and index columns are 32-byte aligned like the reference's (`alignment = 32`, src/soa.toml:17-22,27-32).
@@ -40,6 +40,12 @@ namespace rt
 	{
 		vec3 center;
 		float radius;
+	};
+
+	struct box // muu::bounding_box<float>: centre and half sizes
+	{
+		vec3 center;
+		vec3 extents;
 	};
 
 	struct plane // muu::plane<float>: normal . p + d = 0
@@ -180,5 +186,30 @@ namespace rt
 		const float* center_y() const noexcept { return center_y_.data(); }
 		const float* center_z() const noexcept { return center_z_.data(); }
 		const float* radius() const noexcept { return radius_.data(); }
+	};
+
+	class boxes // drawn by the preview only; mg_ray_tracer's test_boxes never hits (mg_ray_tracer.cpp:89-93)
+	{
+		detail::column<box> value_;
+		detail::column<unsigned> material_;
+		detail::column<float> center_x_, center_y_, center_z_, extents_x_, extents_y_, extents_z_;
+
+	  public:
+		size_t size() const noexcept { return value_.size(); }
+		void push_back(const box& value, unsigned material, float cx, float cy, float cz, float ex, float ey, float ez)
+		{
+			value_.push_back(value);
+			material_.push_back(material);
+			center_x_.push_back(cx), center_y_.push_back(cy), center_z_.push_back(cz);
+			extents_x_.push_back(ex), extents_y_.push_back(ey), extents_z_.push_back(ez);
+		}
+		const box* value() const noexcept { return value_.data(); }
+		const unsigned* material() const noexcept { return material_.data(); }
+		const float* center_x() const noexcept { return center_x_.data(); }
+		const float* center_y() const noexcept { return center_y_.data(); }
+		const float* center_z() const noexcept { return center_z_.data(); }
+		const float* extents_x() const noexcept { return extents_x_.data(); }
+		const float* extents_y() const noexcept { return extents_y_.data(); }
+		const float* extents_z() const noexcept { return extents_z_.data(); }
 	};
 }

@@ -84,6 +84,10 @@ class HipRayTracer:
         )
         return rgba, rgb, stats.as_dict()
 
+    def preview(self, scene: RtHipScene, width: int, height: int, want_rgb: bool = False, out: np.ndarray | None = None):
+        """The one-ray-per-pixel preview (reference src/renderers/rasterizer.cpp) through the same drop-in call."""
+        return self.render(scene, width, height, seed=0, flags=capi.RT_HIP_FLAG_PREVIEW, want_rgb=want_rgb, out=out)
+
     # ---- resident path ------------------------------------------------------------------------------------
     def upload(self, scene: RtHipScene) -> None:
         check(self._lib.rt_hip_scene_upload(self._ctx, C.byref(scene)))

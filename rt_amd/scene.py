@@ -89,6 +89,7 @@ def scene_from_arrays(
     spheres=None,
     planes=None,
     materials=None,
+    boxes=None,
     samples_per_pixel: int = 1,
     max_bounces: int = 10,
     inverse_view_projection=None,
@@ -96,7 +97,8 @@ def scene_from_arrays(
     """Build an rt_hip_scene directly from Python data (tests of ragged / empty / edge-case scenes).
 
     spheres: rows (cx, cy, cz, radius, material); planes: rows (nx, ny, nz, d, material);
-    materials: rows (type, r, g, b, a, roughness, reflectivity).
+    materials: rows (type, r, g, b, a, roughness, reflectivity); boxes: rows (cx, cy, cz, ex, ey, ez, material),
+    drawn by the preview only.
     """
     out = capi.RtHipScene()
     keep = []
@@ -127,6 +129,15 @@ def scene_from_arrays(
     out.material_albedo = col(m[:, 1:5].reshape(-1), np.float32)
     out.material_roughness = col(m[:, 5], np.float32)
     out.material_reflectivity = col(m[:, 6], np.float32)
+    b = np.asarray(boxes if boxes is not None else np.zeros((0, 7)), dtype=np.float64).reshape(-1, 7)
+    out.n_boxes = len(b)
+    out.box_center_x = col(b[:, 0], np.float32)
+    out.box_center_y = col(b[:, 1], np.float32)
+    out.box_center_z = col(b[:, 2], np.float32)
+    out.box_extents_x = col(b[:, 3], np.float32)
+    out.box_extents_y = col(b[:, 4], np.float32)
+    out.box_extents_z = col(b[:, 5], np.float32)
+    out.box_material = col(b[:, 6], np.uint32)
     out.samples_per_pixel = samples_per_pixel
     out.max_bounces = max_bounces
     ivp = np.eye(4, dtype=np.float32) if inverse_view_projection is None else np.asarray(inverse_view_projection, dtype=np.float32)

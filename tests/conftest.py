@@ -66,6 +66,34 @@ boxes = [ { material = 0 } ]
 """
 
 
+# what the preview (RT_HIP_FLAG_PREVIEW) is shown: every primitive kind, boxes in front of and behind other things, one
+# box that the camera looks along the face of, fractional albedos (so that shading is not saturated)
+PREVIEW_SCENE = """
+camera = { position = [0.5, 1.5, 6], direction = [0, -0.15, -1] }
+materials = [
+    { type = 'lambert', albedo = [0.8, 0.8, 0.3] },
+    { type = 'metal', albedo = [0.9, 0.5, 0.2] },
+    { type = 'lambert', albedo = [0.2, 0.4, 0.9] },
+    { type = 'dielectric', albedo = [0.6, 0.9, 0.6] },
+]
+planes = [
+    { material = 0 },
+    { material = 2, position = [0, 0, -8], normal = [0, 0, 1] },
+]
+boxes = [
+    { material = 1, position = [-2, 0.5, 0] },
+    { material = 3, position = [2, 1, -2], extents = [0.5, 1, 0.75] },
+    { material = 2, position = [0.5, 0.25, 3], extents = [0.25, 0.25, 0.25] },
+    { material = 1, position = [0, 3, -7.5], extents = [3, 0.5, 0.5] },
+]
+spheres = [
+    { material = 3, position = [0, 1, 0], radius = 1 },
+    { material = 1, position = [2, 2.4, -2], radius = 0.4 },
+    { material = 0, position = [-2, 1.3, 0], radius = 0.3 },
+]
+"""
+
+
 @pytest.fixture(scope="session")
 def planes_scene():
     import rt_amd

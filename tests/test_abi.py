@@ -27,11 +27,37 @@ def test_header_symbols_all_exported():
 
 
 def test_abi_version_and_struct_sizes():
-    assert capi.hip_lib().rt_hip_abi_version() == 1
-    # LP64 layout of the PODs in include/rt_hip.h
+    assert capi.hip_lib().rt_hip_abi_version() == 2
+    # LP64 layout of the PODs in include/rt_hip.h: spheres, planes, materials, sampling, matrix, boxes
     assert C.sizeof(capi.RtHipPartition) == 12
-    assert C.sizeof(capi.RtHipScene) == 8 * 6 + 8 * 6 + 8 * 5 + 8 + 64
+    assert C.sizeof(capi.RtHipScene) == 8 * 6 + 8 * 6 + 8 * 5 + 8 + 64 + 8 * 8
     assert C.sizeof(capi.RtHipStats) == 4 * 8 + 4 * 4
+
+
+def test_ctypes_mirrors_match_the_header_as_a_c_compiler_sees_it(tmp_path):
+    """sizeof / offsetof of every POD field, printed by a C program compiled against include/rt_hip.h."""
+    import shutil
+    import subprocess
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        pytest.skip("no C compiler")
+    pods = {"rt_hip_scene": capi.RtHipScene, "rt_hip_partition": capi.RtHipPartition, "rt_hip_stats": capi.RtHipStats}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "rt_hip.h"', "int main(void) {"]
+    for c_name, mirror in pods.items():
+        lines.append(f'printf("{c_name} %zu\\n", sizeof({c_name}));')
+        for field, _ in mirror._fields_:
+            lines.append(f'printf("{c_name}.{field} %zu\\n", offsetof({c_name}, {field}));')
+    lines.append("return 0; }")
+    source = tmp_path / "layout.c"
+    source.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-I", str(ROOT / "include"), str(source), "-o", str(exe)], check=True)
+    seen = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for c_name, mirror in pods.items():
+        assert int(seen[c_name]) == C.sizeof(mirror), c_name
+        for field, _ in mirror._fields_:
+            assert int(seen[f"{c_name}.{field}"]) == getattr(mirror, field).offset, f"{c_name}.{field}"
 
 
 def test_last_error_never_null():

@@ -18,6 +18,9 @@ def test_list_shows_the_registered_renderers():
     out = run("--list")
     assert out.returncode == 0
     assert "hip_ray_tracer" in out.stdout and "hip_sm_ray_tracer" in out.stdout and "null_renderer" in out.stdout
+    assert "hip_rasterizer" in out.stdout
+    # `--renderer hip` keeps meaning the path tracer: prefix matching takes the first registered match (src/main.cpp:75-78)
+    assert out.stdout.index("hip_ray_tracer") < out.stdout.index("hip_rasterizer")
 
 
 def test_unknown_renderer_and_missing_scene_fail_like_the_reference():
@@ -66,4 +69,21 @@ def test_hip_sm_ray_tracer_plugin_renders_the_oracle_frame_in_sm_mode(tmp_path):
     got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(45, 80, 3)
     scene = rt_amd.Scene.named("dielectric").set_sampling(6)
     want, _, _ = oracle.render(scene.describe(80, 45), 80, 45, seed=5, want_rgb=False, sm_materials=True)
+    assert np.array_equal(got, unpack(want)[..., :3])
+
+
+@pytest.mark.gpu
+def test_hip_rasterizer_plugin_draws_the_oracle_preview_boxes_included(tmp_path):
+    import rt_amd
+    from oracle import binding as oracle
+    from tests.conftest import PREVIEW_SCENE, unpack
+
+    scene_file = tmp_path / "preview.toml"
+    scene_file.write_text(PREVIEW_SCENE)
+    ppm = tmp_path / "preview.ppm"
+    out = run("--renderer", "hip_ras", "--scene", str(scene_file), "--size", "120x67", "--out", str(ppm))
+    assert out.returncode == 0 and "created renderer: hip_rasterizer" in out.stdout and "error:" not in out.stderr
+    header = b"P6\n120 67\n255\n"
+    got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(67, 120, 3)
+    want, _, _ = oracle.render(rt_amd.Scene.parse(PREVIEW_SCENE).describe(120, 67), 120, 67, want_rgb=False, preview=True)
     assert np.array_equal(got, unpack(want)[..., :3])

@@ -150,3 +150,25 @@ def test_viewport_inverse_view_projection_round_trips():
     # a corner: x offset = near * tan(pi/8) * aspect
     corner = scene.screen_to_world(640, 480, 640, 0, 0.0)
     assert np.allclose(corner, [0.01 * np.tan(np.pi / 8) * 640 / 480, 1 + 0.01 * np.tan(np.pi / 8), 2.99], atol=1e-4)
+
+
+def test_boxes_are_loaded_into_their_columns_with_the_reference_defaults():
+    """reference src/scene.cpp:599-615: position defaults to (0, 1, -3), extents to 0.5 (half sizes), material
+    index checked like every other primitive's."""
+    scene = rt_amd.Scene.parse(
+        """
+materials = [ {}, { type = 'metal' } ]
+boxes = [ {}, { material = 1, position = [1, 2, 3], extents = [0.25, 0.5, 4] }, { extents = 2 } ]
+"""
+    )
+    pod = scene.describe(8, 8)
+    assert pod.n_boxes == 3 and pod.n_spheres == 0 and pod.n_planes == 0
+    assert column(pod.box_center_x, 3).tolist() == [0, 1, 0]
+    assert column(pod.box_center_y, 3).tolist() == [1, 2, 1]
+    assert column(pod.box_center_z, 3).tolist() == [-3, 3, -3]
+    assert column(pod.box_extents_x, 3).tolist() == [0.5, 0.25, 2]
+    assert column(pod.box_extents_y, 3).tolist() == [0.5, 0.5, 2]
+    assert column(pod.box_extents_z, 3).tolist() == [0.5, 4, 2]
+    assert column(pod.box_material, 3, np.uint32).tolist() == [0, 1, 0]
+    with pytest.raises(rt_amd.SceneError, match="material index 5 out-of-range"):
+        rt_amd.Scene.parse("boxes = [ { material = 5 } ]")

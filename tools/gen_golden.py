@@ -16,7 +16,7 @@ sys.path.insert(0, str(ROOT))
 
 import rt_amd  # noqa: E402
 from oracle import binding as oracle  # noqa: E402
-from tests.conftest import PLANES_SCENE  # noqa: E402
+from tests.conftest import PLANES_SCENE, PREVIEW_SCENE  # noqa: E402
 
 OUT = ROOT / "tests" / "golden"
 OUT.mkdir(parents=True, exist_ok=True)
@@ -37,6 +37,12 @@ for fixture, name, width, height, spp, bounces, seed in FRAMES:
         OUT / f"{fixture}.npz", scene=name, width=width, height=height, spp=spp, max_bounces=bounces, seed=seed, rgba=rgba, rgb=rgb, segments=stats["segments"]
     )
     print(fixture, stats)
+
+# the preview (RT_HIP_FLAG_PREVIEW): planes, boxes and spheres, one ray per pixel
+width, height = 96, 54
+rgba, rgb, stats = oracle.render(rt_amd.Scene.parse(PREVIEW_SCENE).describe(width, height), width, height, preview=True)
+np.savez_compressed(OUT / "preview_96x54.npz", width=width, height=height, rgba=rgba, rgb=rgb)
+print("preview_96x54", stats)
 
 seed, pixel, sample = 0x0123456789ABCDEF, 987654, 42
 np.savez_compressed(OUT / "random_stream.npz", seed=np.uint64(seed), pixel=pixel, sample=sample, draws=oracle.random(seed, pixel, sample, 256))
