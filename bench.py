@@ -73,6 +73,7 @@ def main() -> None:
     ap.add_argument("--max-bounces", type=int, default=10)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
+    ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=0, help="1: one frame at a time; 2: consecutive frames alternate between two streams; 0 = 1 on one GPU, 2 on several")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
@@ -106,7 +107,7 @@ def main() -> None:
     pod = scene.describe(args.width, args.height)
     for t in tracers:
         t.upload(pod)  # inputs resident in HBM before the timed region
-    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else 0
+    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else 0)
     frame = distributed.DistributedFrame(tracers, args.width, args.height)
 
     def step():

@@ -148,7 +148,8 @@ enum
 	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup (<= 1024 primitives) */
 	RT_HIP_KERNEL_TILED		= 2, /* primitives streamed from the SoA columns through LDS in tiles (large scenes) */
 	RT_HIP_KERNEL_SMALL		= 3, /* <= 8 spheres, no planes: scene in scalar registers, scan fully unrolled */
-	RT_HIP_KERNEL_PREVIEW	= 4	 /* RT_HIP_FLAG_PREVIEW: one primary ray per pixel, N.L shading */
+	RT_HIP_KERNEL_PREVIEW	= 4, /* RT_HIP_FLAG_PREVIEW: one primary ray per pixel, N.L shading */
+	RT_HIP_KERNEL_STREAMED	= 5	 /* primitives read from the table in HBM/L2 with wave-uniform scalar loads: no staging, no barriers */
 };
 
 /* Render flags.  0 = the parity contract: arithmetic bit-identical to oracle/ (see DESIGN.md §3). */
@@ -174,7 +175,9 @@ enum
 	 * over planes, then boxes, then spheres, shaded 0.25 + 0.75 * albedo * (N . direction to the eye), the sky where
 	 * nothing is hit.  Deterministic: seed, samples_per_pixel and max_bounces are not read; d_rgb_f32 / rgb_f32
 	 * receive the colour before packing.  Partition, gather and assemble work as for the traced frame. */
-	RT_HIP_FLAG_PREVIEW = 1u << 4
+	RT_HIP_FLAG_PREVIEW = 1u << 4,
+	/* force the scalar-streamed kernel (testing) */
+	RT_HIP_FLAG_FORCE_STREAMED = 1u << 5
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

@@ -23,7 +23,8 @@ RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
 RT_HIP_FLAG_PERSISTENT_FRAME = 1 << 2
 RT_HIP_FLAG_SM_MATERIALS = 1 << 3
 RT_HIP_FLAG_PREVIEW = 1 << 4
-KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview"}
+RT_HIP_FLAG_FORCE_STREAMED = 1 << 5
+KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview", 5: "streamed"}
 
 STATUS_NAMES = {
     0: "RT_HIP_OK",

@@ -261,6 +261,7 @@ namespace rt_hip
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
+																	  const float4* __restrict__ geometry, // = s.primitive_geometry, as a plain read-only argument
 																	  uint32_t* __restrict__ out_rgba,
 																	  float* __restrict__ out_rgb,
 																	  device_counters* __restrict__ counters)
@@ -270,7 +271,7 @@ namespace rt_hip
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
 			uint32_t* const lds_scatter = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
-			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (NS == 0 ? s.n_spheres + s.n_planes : tile_primitives);
+			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -334,7 +335,7 @@ namespace rt_hip
 				const bool tracing = mode == lane_trace;
 				candidate tiled_planes = { 0.0f, 0u, false };
 				candidate tiled_spheres = { 0.0f, 0u, false };
-				if (NS < 0 && __syncthreads_or(tracing)) // nothing to stream on the very first trip: no lane holds a ray yet
+				if (NS == -1 && __syncthreads_or(tracing)) // nothing to stream on the very first trip: no lane holds a ray yet
 				{
 					// all 256 threads stage, lanes without a ray just do not scan
 					for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
@@ -372,7 +373,7 @@ namespace rt_hip
 					st.segments++;
 					uint32_t kind;
 					float distance;
-					if (NS < 0)
+					if (NS == -1)
 					{
 						uint32_t index;
 						kind = select_hit(tiled_spheres, tiled_planes, distance, index);
@@ -415,8 +416,10 @@ namespace rt_hip
 					{
 						candidate planes = { 0.0f, 0u, false };
 						candidate spheres = { 0.0f, 0u, false };
-						scan_lds<false>(planes, st.origin, st.dir, lds + s.n_spheres, s.n_planes, 0);
-						scan_lds<true>(spheres, st.origin, st.dir, lds, s.n_spheres, 0);
+						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
+						const float4* const primitives = NS == 0 ? lds : geometry;
+						scan_lds<false>(planes, st.origin, st.dir, primitives + s.n_spheres, s.n_planes, 0);
+						scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
 						uint32_t index;
 						kind = select_hit(spheres, planes, distance, index);
 						fetch_hit<SM>(s, st.origin, st.dir, kind, distance, index, normal, shading, scatter_kind);
@@ -473,7 +476,7 @@ namespace rt_hip
 					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
 				}
 				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
-				if (NS < 0)
+				if (NS == -1)
 				{
 					if (__syncthreads_and(queue_empty)) // the four waves leave together
 						break;
@@ -871,7 +874,7 @@ namespace rt_hip
 							 device_counters* d_counters,
 							 hipStream_t stream)
 		{
-			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, d_rgba8, d_rgb_f32, d_counters);
+			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters);
 		}
 
 		template <int NS>
@@ -897,6 +900,8 @@ namespace rt_hip
 	uint32_t choose_kernel(const device_scene& scene, uint32_t flags)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
+		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
+			return RT_HIP_KERNEL_STREAMED;
 		if (flags & RT_HIP_FLAG_FORCE_TILED)
 			return RT_HIP_KERNEL_TILED;
 		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
@@ -962,6 +967,11 @@ namespace rt_hip
 		{
 			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
 			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			return variant;
+		}
+		if (variant == RT_HIP_KERNEL_STREAMED)
+		{
+			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
 			return variant;
 		}
 		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);

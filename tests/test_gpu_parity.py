@@ -20,6 +20,7 @@ pytestmark = pytest.mark.gpu
 
 FORCE_TILED = capi.RT_HIP_FLAG_FORCE_TILED
 FORCE_RESIDENT = capi.RT_HIP_FLAG_FORCE_RESIDENT
+FORCE_STREAMED = capi.RT_HIP_FLAG_FORCE_STREAMED
 
 
 def assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, what=""):
@@ -131,7 +132,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,width,height,spp,bounces,seed", CASES)
-@pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED], ids=["auto", "resident", "tiled"])
+@pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED, FORCE_STREAMED], ids=["auto", "resident", "tiled", "streamed"])
 def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, bounces, seed, flags):
     scene = planes_scene if name == "planes" else rt_amd.Scene.named(name)
     scene.set_sampling(spp, bounces)
@@ -143,7 +144,9 @@ def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, boun
     assert stats["primary_samples"] == width * height * spp
     assert stats["sphere_tests"] == want_stats["segments"] * pod.n_spheres
     primitives = pod.n_spheres + pod.n_planes
-    if flags == FORCE_TILED or primitives > 1024:
+    if flags == FORCE_STREAMED:
+        expected_kernel = "streamed"
+    elif flags == FORCE_TILED or primitives > 1024:
         expected_kernel = "tiled"
     elif flags == 0 and pod.n_planes == 0 and 1 <= pod.n_spheres <= 8:
         expected_kernel = "small"
@@ -213,7 +216,7 @@ def test_random_scenes_are_bit_exact(tracer, case):
     ivp = camera.describe(width, height).inverse_view_projection[:]
     pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
     seed = int(rng.integers(0, 2**63))
-    for flags in (0, FORCE_RESIDENT, FORCE_TILED, SM):
+    for flags in (0, FORCE_RESIDENT, FORCE_TILED, FORCE_STREAMED, SM, SM | FORCE_STREAMED):
         got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
         want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed, sm_materials=bool(flags & SM))
         # NaNs (e.g. from a ray that starts exactly on a degenerate configuration) must agree in place, any payload
