@@ -45,31 +45,24 @@ namespace rt_hip
 
 	__device__ __forceinline__ float sqrt_core(float x, float& half_rsq)
 	{
-		// Goldschmidt iteration seeded by v_rsq_f32 (1 ulp), residual-corrected: correctly rounded in the band
+		// x * rsq(x) with ONE residual correction.  gfx950's v_rsq_f32 is accurate enough that this is the correctly
+		// rounded square root for every input in the band (the Goldschmidt step hipcc's expansion puts in front of the
+		// correction never changes a result there): tools/exact_math_search.hip tried the shorter forms exhaustively,
+		// rt_hip_kat_exhaustive_math re-checks the one in use on the device the tests run on.
 		const float r = __builtin_amdgcn_rsqf(x);
-		float s = x * r;
-		float h = 0.5f * r;
-		const float e = fma(-h, s, 0.5f);
-		h = fma(h, e, h);
-		s = fma(s, e, s);
+		const float s = x * r;
+		const float h = 0.5f * r;
 		const float d = fma(-s, s, x);
-		s = fma(d, h, s);
 		half_rsq = h;
-		return s;
+		return fma(d, h, s);
 	}
 
 	__device__ __forceinline__ float rcp_core(float x, float seed)
 	{
-		// the refinement steps of the IEEE division expansion for 1/x, without the range scaling
-		float r = seed;
-		const float e0 = fma(-x, r, 1.0f);
-		r = fma(e0, r, r);
-		float q = r;
-		const float e1 = fma(-x, q, 1.0f);
-		q = fma(e1, r, q);
-		const float e2 = fma(-x, q, 1.0f);
-		q = fma(e2, r, q);
-		return q;
+		// v_rcp_f32 with ONE residual correction: the correctly rounded reciprocal for every input in the band on
+		// gfx950 (same exhaustive search; the two further steps of the IEEE division expansion never change a result)
+		const float e = fma(-x, seed, 1.0f);
+		return fma(e, seed, seed);
 	}
 
 	// The general expansions sit behind a branch that is practically never taken (hipcc skips it with one
@@ -109,9 +102,9 @@ namespace rt_hip
 	}
 
 	// == 1.0f / __builtin_sqrtf(x): both roundings kept.  (Seeding the reciprocal with the square root's own
-	// v_rsq_f32 estimate instead of v_rcp_f32 saves a transcendental but is NOT exact: it misses the correctly
-	// rounded quotient for the 120 inputs just below an even power of two — exactly what normalising an already
-	// unit-length direction produces — as rt_hip_kat_exhaustive_math showed.)
+	// reciprocal-square-root estimate instead of v_rcp_f32 saves a transcendental but is NOT exact: it misses the
+	// correctly rounded quotient for the 120 inputs just below an even power of two — exactly what normalising an
+	// already unit-length direction produces — as the exhaustive search showed.)
 	__device__ __forceinline__ float inv_sqrt_rn(float x)
 	{
 		const bool fast = in_fast_band(x);
