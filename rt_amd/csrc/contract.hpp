@@ -142,6 +142,14 @@ namespace rt_hip
 		const float inv = inv_sqrt_in_band(dot(v, v));
 		return v * inv;
 	}
+	// The same from the draws' NUMERATORS k (v = k * 2^-24): scaling by a power of two commutes with every rounding
+	// involved (products, fmas, the correctly rounded square root and reciprocal; nothing leaves the normal range:
+	// 1 <= dot(k,k) < 2^50), so normalize(k * 2^-24) == k * inv_sqrt(dot(k,k)) bit for bit, without the three scalings.
+	__device__ __forceinline__ vec3 normalize_unit_cube_numerators(vec3 k)
+	{
+		const float inv = inv_sqrt_in_band(dot(k, k));
+		return k * inv;
+	}
 
 	// muu::ray::at
 	__device__ __forceinline__ vec3 ray_at(vec3 o, vec3 d, float t) { return { fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z) }; }
@@ -168,12 +176,14 @@ namespace rt_hip
 	constexpr uint32_t sample_stride = draw_stride * 4096u; // mod 2^32
 	__device__ __forceinline__ uint32_t sample_counter(uint32_t pixel, uint32_t sample_index) { return pixel + sample_index * sample_stride; }
 
-	// random<float>(), src/random.hpp:12-17: uniform in [0, 1)
-	__device__ __forceinline__ float next_random(uint32_t& counter)
+	// random<float>(), src/random.hpp:12-17: uniform in [0, 1), as the integer k of u = k * 2^-24 (0 <= k < 2^24, exact)
+	constexpr float random_scale = 0x1.0p-24f;
+	__device__ __forceinline__ float next_random_numerator(uint32_t& counter)
 	{
 		counter += draw_stride;
-		return static_cast<float>(hash32(counter) >> 8) * 0x1.0p-24f;
+		return static_cast<float>(hash32(counter) >> 8);
 	}
+	__device__ __forceinline__ float next_random(uint32_t& counter) { return next_random_numerator(counter) * random_scale; }
 
 	// random_unit_vector(), src/random.hpp:57-66 (positive octant only)
 	__device__ __forceinline__ vec3 random_unit_vector(uint32_t& counter)

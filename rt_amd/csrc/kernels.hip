@@ -490,8 +490,9 @@ namespace rt_hip
 					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
 					uint32_t counter = restart ? sample_counter(st.pixel_key, st.sample) : st.counter;
 					const uint32_t counter_at_start = counter;
-					float d0 = next_random(counter);
-					float d1 = next_random(counter);
+					// (as numerators k of u = k * 2^-24: the scaling folds into the jitter's fma and cancels in the unit vector)
+					float d0 = next_random_numerator(counter);
+					float d1 = next_random_numerator(counter);
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
 					bool absorbed = false;
 					bool unit_length = false; // `toward` is used as it is (sm's dielectric_scatter does not normalise)
@@ -526,7 +527,7 @@ namespace rt_hip
 							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
 						}
 						counter = counter_at_start + draw_stride; // only d0 was consumed
-						toward = (d0 < reflect_prob) ? reflected : refracted;
+						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
 						unit_length = true;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
 						st.origin = hit_pos;
@@ -534,14 +535,14 @@ namespace rt_hip
 					else if (shade)
 					{
 						const bool metal = scatter_kind == scatter_metal;
-						float d2 = next_random(counter);
+						float d2 = next_random_numerator(counter);
 						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
 						{
-							d0 = next_random(counter);
-							d1 = next_random(counter);
-							d2 = next_random(counter);
+							d0 = next_random_numerator(counter);
+							d1 = next_random_numerator(counter);
+							d2 = next_random_numerator(counter);
 						}
-						const vec3 u = normalize_unit_cube_draw({ d0, d1, d2 });
+						const vec3 u = normalize_unit_cube_numerators({ d0, d1, d2 });
 						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
 						vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
 						if (metal)
@@ -556,7 +557,7 @@ namespace rt_hip
 					else if (restart)
 					{
 						// worker lambda :189-193 — jittered position, un-project to near and far, build the primary ray
-						float jx = 0.5f, jy = 0.5f; // sample 0 goes through the pixel centre and draws nothing
+						float jx = 0x1.0p23f, jy = 0x1.0p23f; // sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing
 						if (st.sample)
 						{
 							jx = d0;
@@ -564,8 +565,8 @@ namespace rt_hip
 						}
 						else
 							counter = counter_at_start;
-						const float px = st.fx + jx;
-						const float py = st.fy + jy;
+						const float px = fma(jx, random_scale, st.fx); // == fx + jx * 2^-24: the product is exact
+						const float py = fma(jy, random_scale, st.fy);
 						const float ndc_x = fma(px, p.sx, -1.0f);
 						const float ndc_y = fma(py, p.neg_sy, 1.0f);
 						float near_row[3], far_row[3];
