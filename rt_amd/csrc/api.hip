@@ -551,6 +551,13 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	f.inv_w_near = f.uniform_w ? 1.0f / f.k_near[3] : 0.0f;
 	f.inv_w_far = f.uniform_w ? 1.0f / f.k_far[3] : 0.0f;
 
+	if (!(flags & RT_HIP_FLAG_PREVIEW))
+	{
+		// a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete: 4 waves x items x 12 bytes
+		const queue_params tiles = choose_queue(f.samples_per_pixel, static_cast<uint64_t>(width) * f.local_rows, choose_kernel(ctx->scene, flags) == RT_HIP_KERNEL_TILED);
+		if (4ull * (static_cast<uint64_t>(tiles.chunks) << tiles.pixels_log2) * 12u > 48u * 1024u)
+			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %u samples per pixel are more than the kernels hold chunk sums for (4096; the reference clamps to 1000, src/scene.cpp:544)", f.samples_per_pixel);
+	}
 	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
 	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
 	uint32_t variant = RT_HIP_KERNEL_PREVIEW;

@@ -128,6 +128,8 @@ CASES = [
     ("planes", 128, 72, 8, 6, 8),  # planes + spheres + metal + a box entry that mg ignores
     ("synthetic-1000", 96, 54, 2, 10, 9),  # resident kernel at its LDS capacity (1000 <= 1024 primitives)
     ("synthetic-2500", 64, 36, 2, 10, 10),  # tiled kernel: 3 LDS tiles, ragged last tile
+    ("basic", 150, 97, 1000, 10, 11),  # the loader's maximum spp: 63 chunks per pixel, 4-pixel tiles
+    ("basic", 300, 200, 20, 10, 12),
 ]
 
 
@@ -443,6 +445,12 @@ def test_bad_arguments_are_refused(tracer):
     with pytest.raises(rt_amd.RtHipError) as err:
         rt_amd.HipRayTracer(device=99)
     assert err.value.status == 2  # RT_HIP_NO_DEVICE
+    # more samples per pixel than the kernels keep chunk sums for (the reference's loader clamps to 1000)
+    huge = rt_amd.Scene.named("basic").describe(16, 16)
+    huge.samples_per_pixel = 100000
+    with pytest.raises(rt_amd.RtHipError) as err:
+        tracer.render(huge, 16, 16)
+    assert err.value.status == 5 and "samples per pixel" in str(err.value)
     # the context is still usable after refused calls
     rgba, _, _ = tracer.render(pod, 16, 16)
     assert rgba.shape == (16, 16)
