@@ -532,6 +532,10 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	f.rank = p.rank;
 	f.world = p.world;
 	f.stripe_rows = p.stripe_rows;
+	f.stripe_shift = 0xFFFFFFFFu;
+	if ((p.stripe_rows & (p.stripe_rows - 1u)) == 0u)
+		for (f.stripe_shift = 0; (1u << f.stripe_shift) != p.stripe_rows; f.stripe_shift++)
+		{}
 	f.samples_per_pixel = ctx->samples_per_pixel;
 	f.max_bounces = ctx->max_bounces;
 	f.frame_key = frame_key(seed);

@@ -188,8 +188,13 @@ namespace rt_hip
 			uint32_t segments;
 		};
 
+		// image row of row `local_row` of this rank's compact buffer (rt_hip_partition).  All branches are wave-uniform.
 		__device__ __forceinline__ uint32_t global_row(uint32_t local_row, const frame_params& p)
 		{
+			if (p.world == 1u)
+				return local_row; // the whole frame: no arithmetic at all
+			if (p.stripe_shift != 0xFFFFFFFFu) // stripes of 2^k rows (the default, 8): shifts instead of a division
+				return ((((local_row >> p.stripe_shift) * p.world) + p.rank) << p.stripe_shift) | (local_row & ((1u << p.stripe_shift) - 1u));
 			return ((local_row / p.stripe_rows) * p.world + p.rank) * p.stripe_rows + (local_row % p.stripe_rows);
 		}
 
