@@ -109,6 +109,7 @@ namespace
 struct rt_hip_ctx
 {
 	int device = 0;
+	uint32_t compute_units = 256;
 
 	// the scene, resident in HBM: one buffer holding every column back to back (256-byte aligned starts)
 	device_buffer scene_columns;
@@ -194,6 +195,7 @@ extern "C" rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device)
 	if (!ctx)
 		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create: out of host memory");
 	ctx->device = device;
+	ctx->compute_units = props.multiProcessorCount > 0 ? static_cast<uint32_t>(props.multiProcessorCount) : 256u;
 	hipError_t e = ctx->counters.reserve(sizeof(device_counters));
 	if (e == hipSuccess)
 		e = hipEventCreate(&ctx->render_begin);
@@ -557,10 +559,15 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		// a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete: 4 waves x items x 12 bytes
-		const queue_params tiles = choose_queue(f.samples_per_pixel, static_cast<uint64_t>(width) * f.local_rows, choose_kernel(ctx->scene, flags) == RT_HIP_KERNEL_TILED);
-		if (4ull * (static_cast<uint64_t>(tiles.chunks) << tiles.pixels_log2) * 12u > 48u * 1024u)
+		// a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
+		const uint32_t variant = choose_kernel(ctx->scene, flags);
+		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
+		const queue_params tiles = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);
+		const uint64_t slot_bytes = 4ull * (big_scene ? 2u : 1u) * (static_cast<uint64_t>(tiles.chunks) << tiles.pixels_log2) * 12u;
+		if (slot_bytes > 48u * 1024u)
 			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %u samples per pixel are more than the kernels hold chunk sums for (4096; the reference clamps to 1000, src/scene.cpp:544)", f.samples_per_pixel);
+		if (static_cast<uint64_t>(tiles.tiles_x) * tiles.tiles_y > 0x7FFFFFFFull) // the tile queue's 32-bit head
+			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %ux%u at %u samples per pixel has too many pixel tiles", width, height, f.samples_per_pixel);
 	}
 	RT_HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, sizeof(device_counters), s));
 	RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
@@ -568,7 +575,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	if (flags & RT_HIP_FLAG_PREVIEW)
 		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
 	else
-		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), ctx->compute_units, s);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
 	ctx->render_recorded = true;

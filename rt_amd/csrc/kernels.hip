@@ -16,7 +16,7 @@
 //     once for the wave; only what really differs runs under its own lane mask);
 //   * the closest-hit scan reads every primitive with a WAVE-UNIFORM operand and skips a primitive's square-root half
 //     when no lane of the wave can hit it (ballots combined on the scalar unit);
-//   * one kernel template, three modes chosen by scene size:
+//   * one kernel template, its modes chosen by scene size:
 //       small    (<= 8 spheres, no planes: basic.toml, dielectric.toml): the spheres arrive as kernel arguments and
 //                live in SGPRs; the scan is fully unrolled straight-line code with scalar operands; only the
 //                per-lane lookups of the winning sphere go through LDS;
@@ -24,12 +24,18 @@
 //                reads them as broadcast ds_read_b128 (no bank conflicts), four spheres per group;
 //       tiled    (anything larger): primitives stream from the SoA columns in HBM/L2 through one LDS tile of 1024
 //                shared by the workgroup's waves (coalesced dword loads per column, radius squared on the way in);
-//                the workgroup moves in lock step, one path segment per trip, with barriers around each tile.
+//                the workgroup moves in lock step, one path segment per trip, with barriers around each tile;
+//       streamed (opt-in): the resident loop reading the primitive table with wave-uniform scalar loads from HBM/L2.
+//     The two big-scene modes are launched persistent and pull pixel tiles from a launch-wide queue, two open per wave
+//     ("rolling tiles", see render_queue): there a trip costs one scan over all primitives whatever the number of lanes
+//     holding a ray, so lane occupancy is everything.
 // No MFMA: this is intersection arithmetic (subtract / dot / compare / sqrt), not a contraction.
 #include "kernels.hpp"
 #include "contract.hpp"
 
 #include "../../include/rt_hip.h"
+
+#include <algorithm>
 
 namespace rt_hip
 {
@@ -253,14 +259,31 @@ namespace rt_hip
 		// computes which chunk cannot change a result.
 		//
 		// NS > 0: `small` kernel, NS spheres in SGPRs (kernel argument).  NS == 0: `resident` kernel, all primitives in LDS.
-		// NS < 0: `tiled` kernel — the primitives stream from the SoA columns in HBM/L2 through one LDS tile shared by the
+		// NS == -1: `tiled` kernel — the primitives stream from the SoA columns in HBM/L2 through one LDS tile shared by the
 		// workgroup's four waves (coalesced dword per lane per column, radius squared on the way in); every wave still
 		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
-		// each tile, until all four queues are empty.
+		// each tile, until all four waves are done.  NS == -2: `streamed` kernel — the resident loop reading the primitive
+		// table from HBM/L2 with wave-uniform scalar loads.
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
 		// launch bound: 8 waves per SIMD, i.e. at most 64 VGPRs — the scans are latency-bound chains and want the waves.
-		// The tiled mode's LDS tile (16 KB + chunk slots per workgroup) admits 5 workgroups per CU anyway: it gets the
-		// registers of 5 waves per SIMD and needs no scratch.
+		// The big-scene modes get the registers of 5 waves per SIMD and need no scratch.
+		//
+		// ROLLING TILES (NS < 0).  In a big scene a trip is one closest-hit scan over all primitives — the same cost for a
+		// wave with one lane holding a ray as for a wave with 64 — so what matters is that every lane holds a ray in every
+		// trip.  The big-scene kernels are therefore launched persistent: every wave pulls pixel tile after pixel tile from
+		// one launch-wide counter and keeps TWO tiles open — lanes that find the current tile handed out start on the next
+		// one while the stragglers of the previous tile finish — and folds a tile's chunk sums into its pixels when the
+		// tile's last item comes in.  Lanes idle only at the very end of the launch.  (For small scenes the same scheme is
+		// SLOWER: there the per-trip cost is the shading code, and lanes that never start together lose the phase
+		// coherence that keeps it short — profiles/r01/queue_shape_sweep.txt.  They keep one tile per wave.)
+		__device__ __forceinline__ uint32_t fetch_tile(device_counters* counters) // call converged
+		{
+			uint32_t id = 0;
+			if ((threadIdx.x & 63u) == 0)
+				id = atomicAdd(&counters->next_tile, 1u);
+			return __builtin_amdgcn_readfirstlane(id);
+		}
+
 		template <int NS, bool SM>
 		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : 8) void render_queue(const frame_params p,
 																	  const queue_params q,
@@ -297,27 +320,75 @@ namespace rt_hip
 			}
 			__syncthreads();
 
+			constexpr bool ROLLING = NS < 0;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
-			const uint32_t items = q.chunks << q.pixels_log2; // P x K
-			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * items * 3u;
-
-			// this wave's pixel tile; workgroups are handed out bottom row first: the lower part of a frame is usually
-			// the expensive one (ground under sky), and starting with it keeps the cheap sky tiles for the tail
+			const uint32_t items = q.chunks << q.pixels_log2; // of one pixel tile: P x K
+			// chunk-sum slots of this wave's tile (two open tiles when rolling)
+			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * (ROLLING ? 2u * items : items) * 3u;
 			const uint32_t tile_w = 1u << q.tile_w_log2;
 			const uint32_t tile_h = (1u << q.pixels_log2) >> q.tile_w_log2;
+
+			// one tile per wave: workgroups are handed out bottom row first — the lower part of a frame is usually the
+			// expensive one (ground under sky), and starting with it keeps the cheap sky tiles for the tail
 			const uint32_t tile_x0 = (blockIdx.x * 4u + wave) * tile_w;
 			const uint32_t tile_y0 = (gridDim.y - 1u - blockIdx.y) * tile_h;
+			uint32_t next_item = 0; // wave-uniform queue head
+
+			// rolling tiles: ids run bottom row first
+			const uint32_t total_tiles = q.tiles_x * q.tiles_y;
+			const auto tile_origin = [&](uint32_t id, uint32_t& x0, uint32_t& y0)
+			{
+				const uint32_t row = id / q.tiles_x;
+				x0 = (id - row * q.tiles_x) << q.tile_w_log2;
+				y0 = (q.tiles_y - 1u - row) * tile_h;
+			};
+			uint32_t tile0 = 0, tile1 = 0;		 // ids of the tiles in the two slot buffers
+			uint32_t pending0 = 0, pending1 = 0; // their items not yet completed; 0 = the buffer is free
+			uint32_t cur = 1;					 // buffer being handed out
+			uint32_t cur_next = items;			 // its next item (== items: all handed out)
+			uint32_t cur_x0 = 0, cur_y0 = 0;	 // its pixel origin
+			bool dry = false;					 // the launch-wide queue has run out
+			uint32_t prefetched = 0;			 // the id the next opening will use: the atomic's latency is off the path
+			if (ROLLING)
+				prefetched = fetch_tile(counters);
 
 			lane_state st;
 			st.segments = 0;
-			uint32_t next_item = 0; // wave-uniform queue head
-			uint32_t item = 0;		// item in flight on this lane
+			uint32_t slot = 0;	  // chunk-sum slot of the item in flight on this lane ([buffer * items +] item)
+			bool holding = false; // rolling: the lane has been given an item that is not yet accounted for as completed
 			// what the lane does in the current trip:
 			//   free    - between items                       restart - has a sample to start (needs a primary ray)
 			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
 			enum : uint32_t { lane_free, lane_restart, lane_trace, lane_retired };
 			uint32_t mode = lane_free;
+
+			// all items of a tile are in: fold the chunk sums of each pixel in chunk order and write it (:195-200)
+			const auto fold_tile = [&](const float* sums, uint32_t x0, uint32_t y0)
+			{
+				for (uint32_t pixel = lane; pixel < (1u << q.pixels_log2); pixel += 64u)
+				{
+					const uint32_t lx = x0 + (pixel & (tile_w - 1u));
+					const uint32_t ly = y0 + (pixel >> q.tile_w_log2);
+					if (lx < p.width && ly < p.local_rows)
+					{
+						vec3 colour = { sums[pixel * 3u], sums[pixel * 3u + 1u], sums[pixel * 3u + 2u] };
+						for (uint32_t c = 1; c < q.chunks; c++)
+						{
+							const uint32_t at = ((c << q.pixels_log2) + pixel) * 3u;
+							colour = colour + vec3{ sums[at], sums[at + 1u], sums[at + 2u] };
+						}
+						finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+					}
+				}
+			};
+			const auto fold_rolling = [&](uint32_t buffer, uint32_t id)
+			{
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the sums were parked by other lanes of this wave
+				uint32_t x0, y0;
+				tile_origin(id, x0, y0);
+				fold_tile(slots + buffer * items * 3u, x0, y0);
+			};
 
 			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
 			const auto end_sample = [&](vec3 contribution)
@@ -327,9 +398,9 @@ namespace rt_hip
 					mode = lane_restart;
 				else
 				{
-					slots[item * 3u + 0u] = st.chunk_sum.x;
-					slots[item * 3u + 1u] = st.chunk_sum.y;
-					slots[item * 3u + 2u] = st.chunk_sum.z;
+					slots[slot * 3u + 0u] = st.chunk_sum.x;
+					slots[slot * 3u + 1u] = st.chunk_sum.y;
+					slots[slot * 3u + 2u] = st.chunk_sum.z;
 					mode = lane_free;
 				}
 			};
@@ -450,35 +521,96 @@ namespace rt_hip
 
 				// ---- hand out items to free lanes (converged): a lane whose chunk just ended with a miss restarts right below ----
 				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
-				if (asking != 0)
+				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
+				const auto take_item = [&](uint32_t item, uint32_t x0, uint32_t y0)
+				{
+					const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
+					const uint32_t chunk = item >> q.pixels_log2;
+					const uint32_t lx = x0 + (pixel & (tile_w - 1u));
+					const uint32_t ly = y0 + (pixel >> q.tile_w_log2);
+					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+					if (lx < p.width && ly < p.local_rows)
+					{
+						const uint32_t gy = global_row(ly, p);
+						st.fx = static_cast<float>(lx);
+						st.fy = static_cast<float>(gy);
+						st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+						st.sample = chunk * sample_chunk;
+						st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+						mode = lane_restart;
+					}
+					// else: a pixel outside the frame — the item is empty, ask again next trip
+				};
+				if (!ROLLING && asking != 0)
 				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
 					if (mode == lane_free)
 					{
-						item = next_item + rank;
-						if (item >= items)
+						slot = next_item + rank;
+						if (slot >= items)
 							mode = lane_retired;
 						else
-						{
-							const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
-							const uint32_t chunk = item >> q.pixels_log2;
-							const uint32_t lx = tile_x0 + (pixel & (tile_w - 1u));
-							const uint32_t ly = tile_y0 + (pixel >> q.tile_w_log2);
-							st.chunk_sum = { 0.0f, 0.0f, 0.0f };
-							if (lx < p.width && ly < p.local_rows)
-							{
-								const uint32_t gy = global_row(ly, p);
-								st.fx = static_cast<float>(lx);
-								st.fy = static_cast<float>(gy);
-								st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
-								st.sample = chunk * sample_chunk;
-								st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
-								mode = lane_restart;
-							}
-							// else: a pixel outside the frame — the item is empty, ask again next trip
-						}
+							take_item(slot, tile_x0, tile_y0);
 					}
 					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
+				}
+				if (ROLLING && asking != 0)
+				{
+					// items completed since the last hand-out; a tile whose last item is in gets folded and its buffer freed
+					const bool completed = mode == lane_free && holding;
+					const uint32_t done0 = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(completed && slot < items)));
+					const uint32_t done1 = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(completed && slot >= items)));
+					holding = holding && mode != lane_free;
+					if (done0 != 0)
+					{
+						pending0 -= done0;
+						if (pending0 == 0)
+							fold_rolling(0u, tile0);
+					}
+					if (done1 != 0)
+					{
+						pending1 -= done1;
+						if (pending1 == 0)
+							fold_rolling(1u, tile1);
+					}
+
+					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
+					const uint32_t want = static_cast<uint32_t>(__builtin_popcountll(asking));
+					uint32_t served = 0; // asking lanes given an item so far, in rank order
+					while (served < want)
+					{
+						if (cur_next == items) // the current tile is handed out: open the next one in the other buffer
+						{
+							if (dry || (cur ? pending0 : pending1) != 0) // ...unless its previous tile still has items in flight
+								break;
+							if (prefetched >= total_tiles)
+							{
+								dry = true;
+								break;
+							}
+							cur ^= 1u;
+							if (cur)
+								tile1 = prefetched, pending1 = items;
+							else
+								tile0 = prefetched, pending0 = items;
+							tile_origin(prefetched, cur_x0, cur_y0);
+							cur_next = 0;
+							prefetched = fetch_tile(counters);
+						}
+						const uint32_t take = min(want - served, items - cur_next); // >= 1: the loop always advances
+						if (mode == lane_free && rank - served < take) // served <= rank < served + take
+						{
+							const uint32_t item = cur_next + (rank - served);
+							slot = cur * items + item;
+							holding = true; // (an item outside the frame stays `free` and counts as completed at the next hand-out)
+							take_item(item, cur_x0, cur_y0);
+						}
+						served += take;
+						cur_next += take;
+					}
+					// lanes left without an item while the queue is not dry (the other buffer is still draining) ask again next trip
+					if (dry && mode == lane_free && !holding)
+						mode = lane_retired;
 				}
 				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
 				if (NS == -1)
@@ -612,22 +744,11 @@ namespace rt_hip
 				}
 			}
 
-			// ---- fold the chunk sums of each pixel in chunk order and write the pixel (:195-200) ------------------------------
-			__syncthreads();
-			if (lane < (1u << q.pixels_log2))
+			// ---- one tile per wave: fold and write its pixels now (rolling tiles were folded as their last item came in) ----
+			if (!ROLLING)
 			{
-				const uint32_t lx = tile_x0 + (lane & (tile_w - 1u));
-				const uint32_t ly = tile_y0 + (lane >> q.tile_w_log2);
-				if (lx < p.width && ly < p.local_rows)
-				{
-					vec3 colour = { slots[lane * 3u], slots[lane * 3u + 1u], slots[lane * 3u + 2u] };
-					for (uint32_t c = 1; c < q.chunks; c++)
-					{
-						const uint32_t slot = ((c << q.pixels_log2) + lane) * 3u;
-						colour = colour + vec3{ slots[slot], slots[slot + 1u], slots[slot + 2u] };
-					}
-					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
-				}
+				__syncthreads();
+				fold_tile(slots, tile_x0, tile_y0);
 			}
 			add_segments(counters, st.segments);
 		}
@@ -873,13 +994,28 @@ namespace rt_hip
 							 const queue_params& queue,
 							 const small_scene& small,
 							 const device_scene& scene,
-							 dim3 grid,
+							 dim3 grid, // small scenes: the grid of tiles; big scenes: x = the most workgroups the tiles can occupy
 							 size_t lds_bytes,
 							 uint32_t* d_rgba8,
 							 float* d_rgb_f32,
 							 device_counters* d_counters,
+							 uint32_t compute_units,
 							 hipStream_t stream)
 		{
+			if (NS < 0)
+			{
+				// persistent launch: exactly what the device keeps resident (surplus workgroups would only find the queue dry)
+				static size_t asked_for = ~static_cast<size_t>(0);
+				static int per_cu = 0;
+				if (asked_for != lds_bytes)
+				{
+					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes) != hipSuccess || per_cu < 1)
+						per_cu = 4;
+					(void)hipGetLastError();
+					asked_for = lds_bytes;
+				}
+				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(per_cu)));
+			}
 			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters);
 		}
 
@@ -894,12 +1030,13 @@ namespace rt_hip
 						  uint32_t* d_rgba8,
 						  float* d_rgb_f32,
 						  device_counters* d_counters,
+						  uint32_t compute_units,
 						  hipStream_t stream)
 		{
 			if (sm)
-				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
 			else
-				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
 		}
 	}
 
@@ -917,21 +1054,37 @@ namespace rt_hip
 		return RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels, bool tiled)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene)
 	{
-		// K chunks per pixel; P pixels per wave.  A queue of about 256 items (4 per lane) keeps the lanes of a wave
-		// evenly busy; a launch also wants several tens of thousands of waves to balance over 1024 SIMDs, so smaller
-		// frames get queues of 128 items (measured on 1920x1080 and 960x540 at 64 and 256 spp: profiles/r01/queue_shape_sweep.txt).
 		queue_params q{};
-		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk;
-		uint32_t pixels_log2 = 6; // 64 pixels = 8 x 8
-		while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
-			pixels_log2--;
-		// (the tiled kernel's workgroups advance in lock step and are long-lived either way: they keep the full queues)
-		if (!tiled && pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
-			pixels_log2--;
+		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk; // K chunks per pixel
+		uint32_t pixels_log2;
+		if (big_scene)
+		{
+			// rolling tiles: at least 128 items per tile (two per lane) — with two tiles open per wave the stragglers of
+			// one tile are then normally in before the next one is handed out; otherwise as small as possible (the queue
+			// balances the chip at tile granularity, and the slots of two tiles per wave live in LDS)
+			pixels_log2 = 0;
+			while (pixels_log2 < 7u && (q.chunks << pixels_log2) < 128u)
+				pixels_log2++;
+		}
+		else
+		{
+			// one tile per wave: a queue of about 256 items (4 per lane) keeps the lanes of a wave evenly busy; a launch
+			// also wants several tens of thousands of waves to balance over 1024 SIMDs, so smaller frames get queues of
+			// 128 items (measured on 1920x1080 and 960x540 at 64 and 256 spp: profiles/r01/queue_shape_sweep.txt)
+			pixels_log2 = 6; // 64 pixels = 8 x 8
+			while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
+				pixels_log2--;
+			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
+			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
+				pixels_log2--;
+		}
 		q.pixels_log2 = pixels_log2;
-		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 8x8, 8x4, 4x4, 4x2, 2x2
+		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+		const uint32_t tile_w = 1u << q.tile_w_log2, tile_h = (1u << pixels_log2) >> q.tile_w_log2;
+		q.tiles_x = (width + tile_w - 1u) / tile_w;
+		q.tiles_y = (local_rows + tile_h - 1u) / tile_h;
 		return q;
 	}
 
@@ -942,45 +1095,50 @@ namespace rt_hip
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
+						   uint32_t compute_units,
 						   hipStream_t stream)
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
 		const uint32_t variant = choose_kernel(scene, flags);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, static_cast<uint64_t>(frame.width) * frame.local_rows, variant == RT_HIP_KERNEL_TILED);
-		const uint32_t tile_w = 1u << queue.tile_w_log2;
-		const uint32_t tile_h = (1u << queue.pixels_log2) >> queue.tile_w_log2;
-		const dim3 grid((frame.width + 4u * tile_w - 1u) / (4u * tile_w), (frame.local_rows + tile_h - 1u) / tile_h);
-		const size_t slot_bytes = static_cast<size_t>(block_threads / 64u) * (queue.chunks << queue.pixels_log2) * 3u * sizeof(float);
+		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
+		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene);
+		const uint32_t items = queue.chunks << queue.pixels_log2;
+		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
+		// the device keeps resident, and no more waves than tiles
+		const uint64_t total_tiles = static_cast<uint64_t>(queue.tiles_x) * queue.tiles_y;
+		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_tiles + 3u) / 4u))) // capped to the resident count at launch
+									: dim3((queue.tiles_x + 3u) / 4u, queue.tiles_y);
+		const size_t slot_bytes = static_cast<size_t>(block_threads / 64u) * (big_scene ? 2u : 1u) * items * 3u * sizeof(float);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
 			switch (scene.n_spheres)
 			{
-				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
-				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream); break;
+				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
 			}
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
 			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
-			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_STREAMED)
 		{
-			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
 			return variant;
 		}
-		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, stream);
+		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
 		return variant;
 	}
 

@@ -83,18 +83,23 @@ namespace rt_hip
 	// pixel sums are taken in chunks of this many consecutive samples (arithmetic contract; see oracle/cpu_ref.cpp)
 	constexpr uint32_t sample_chunk = 16;
 
-	// shape of the per-wave work queue of the small / resident kernels
+	// Work distribution.  The frame is cut into pixel tiles of P = 2^pixels_log2 pixels; a tile is P x K work items
+	// (K = sample chunks per pixel).  Small scenes: one tile per wave, launched as a grid of tiles.  Big scenes (tiled /
+	// streamed kernels): a persistent launch whose waves pull tiles from one launch-wide queue (device_counters::next_tile),
+	// tile ids running bottom row first.
 	struct queue_params
 	{
-		uint32_t chunks;	  // K: sample chunks per pixel = ceil(spp / sample_chunk)
-		uint32_t pixels_log2; // a wave owns P = 2^pixels_log2 pixels (a tile of 2^tile_w_log2 columns)
-		uint32_t tile_w_log2;
+		uint32_t chunks;		   // K = ceil(spp / sample_chunk)
+		uint32_t pixels_log2;	   // P
+		uint32_t tile_w_log2;	   // a tile is 2^tile_w_log2 columns wide
+		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
 	};
-	queue_params choose_queue(uint32_t samples_per_pixel, uint64_t pixels, bool tiled);
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene);
 
 	struct device_counters
 	{
 		unsigned long long segments;
+		unsigned int next_tile; // head of the tile queue of the big-scene kernels; zeroed with the rest before every launch
 	};
 
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
@@ -111,6 +116,7 @@ namespace rt_hip
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
+						   uint32_t compute_units, // of the device: the big-scene kernels are launched persistent
 						   hipStream_t stream);
 
 	// RT_HIP_FLAG_PREVIEW: one ray per pixel, reference src/renderers/rasterizer.cpp:24-85

@@ -130,6 +130,8 @@ CASES = [
     ("synthetic-2500", 64, 36, 2, 10, 10),  # tiled kernel: 3 LDS tiles, ragged last tile
     ("basic", 150, 97, 1000, 10, 11),  # the loader's maximum spp: 63 chunks per pixel, 4-pixel tiles
     ("basic", 300, 200, 20, 10, 12),
+    ("synthetic-1100", 1024, 640, 1, 10, 13),  # tiled / streamed: 5120 pixel tiles for <= 7168 persistent waves ...
+    ("synthetic-1100", 1500, 1000, 2, 10, 14),  # ... and 11 719: every wave re-opens its two tile buffers several times
 ]
 
 
