@@ -36,6 +36,7 @@
 #include "../../include/rt_hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 namespace rt_hip
 {
@@ -1070,15 +1071,21 @@ namespace rt_hip
 		}
 		else
 		{
-			// one tile per wave: a queue of about 256 items (4 per lane) keeps the lanes of a wave evenly busy; a launch
-			// also wants several tens of thousands of waves to balance over 1024 SIMDs, so smaller frames get queues of
-			// 128 items (measured on 1920x1080 and 960x540 at 64 and 256 spp: profiles/r01/queue_shape_sweep.txt)
+			// one tile per wave.  256 items (4 per lane) keep the lanes of a wave evenly busy, but a launch also needs enough
+			// waves: the device holds 8192 at a time, a wave lives as long as its longest lane, and the launch ends with
+			// about one wave lifetime of tail.  Measured on the headline frame and on its 1/2, 1/4, 1/8 shares at 256 and
+			// 64 spp (profiles/r01/queue_shape_sweep.txt): the largest of 256 / 128 / 64 items that still gives
+			// 6 x 8192 / 3 x 8192 waves wins every case.
 			pixels_log2 = 6; // 64 pixels = 8 x 8
 			while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
 				pixels_log2--;
 			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
-			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 65536u)
+			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 49152u)
 				pixels_log2--;
+			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 64u && (pixels >> pixels_log2) < 24576u)
+				pixels_log2--;
+			if (const char* e = std::getenv("RT_HIP_PIXELS_LOG2")) // experiments only (tools/gpu_partition_times.py)
+				pixels_log2 = static_cast<uint32_t>(std::atoi(e));
 		}
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
