@@ -621,9 +621,12 @@ extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_s
 		ctx->stats.render_ms = ms;
 		device_counters host{};
 		RT_HIP_TRY(hipMemcpy(&host, ctx->counters.ptr, sizeof(host), hipMemcpyDeviceToHost));
-		ctx->stats.segments = host.segments;
-		ctx->stats.sphere_tests = host.segments * ctx->scene.n_spheres;
-		ctx->stats.plane_tests = host.segments * ctx->scene.n_planes;
+		uint64_t segments = 0;
+		for (const unsigned long long part : host.segments)
+			segments += part;
+		ctx->stats.segments = segments;
+		ctx->stats.sphere_tests = segments * ctx->scene.n_spheres;
+		ctx->stats.plane_tests = segments * ctx->scene.n_planes;
 	}
 	*out_stats = ctx->stats;
 	return ok();

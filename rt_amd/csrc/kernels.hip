@@ -227,7 +227,7 @@ namespace rt_hip
 			for (int offset = 32; offset > 0; offset >>= 1)
 				total += __shfl_down(total, offset, 64);
 			if ((threadIdx.x & 63u) == 0 && total)
-				atomicAdd(&counters->segments, total);
+				atomicAdd(&counters->segments[(blockIdx.x + blockIdx.y * 7u + (threadIdx.x >> 6)) % device_counters::segment_counters], total);
 		}
 
 		// lookups of the winning primitive from the global per-primitive tables (one indexed read each)
@@ -853,7 +853,10 @@ namespace rt_hip
 				}
 				out_rgba[o] = pack_rgba8888(colour);
 			}
-			add_segments(counters, alive ? 1u : 0u);
+			// one closest-hit query per pixel: the count is known, so a single store stands in for the per-wave atomics of the
+			// render kernels (at one ray per pixel their serialisation on one address would be most of the launch: 0.40 vs 0.02 ms)
+			if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+				counters->segments[0] = static_cast<unsigned long long>(p.local_rows) * p.width;
 		}
 
 		// ---- multi-GPU assemble: rank-major compact stripes -> frame ------------------------------------------------
@@ -1071,18 +1074,16 @@ namespace rt_hip
 		}
 		else
 		{
-			// one tile per wave.  256 items (4 per lane) keep the lanes of a wave evenly busy, but a launch also needs enough
-			// waves: the device holds 8192 at a time, a wave lives as long as its longest lane, and the launch ends with
-			// about one wave lifetime of tail.  Measured on the headline frame and on its 1/2, 1/4, 1/8 shares at 256 and
-			// 64 spp (profiles/r01/queue_shape_sweep.txt): the largest of 256 / 128 / 64 items that still gives
-			// 6 x 8192 / 3 x 8192 waves wins every case.
-			pixels_log2 = 6; // 64 pixels = 8 x 8
-			while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 256u)
+			// one tile per wave.  A wave lives as long as its longest lane and the launch ends with about one wave lifetime
+			// of tail, so waves should be short — but with fewer than two items per lane the lanes of a wave end at very
+			// different times.  Measured on the headline frame and on its 1/2, 1/4, 1/8 shares at 256, 64 and 16 spp
+			// (profiles/r01/queue_shape_sweep.txt): 128 items per wave, and 64 when that would give fewer than 6 x 8192
+			// waves (8192 = what the device holds at a time), win or tie every case.
+			pixels_log2 = 7; // 128 pixels = 16 x 8
+			while (pixels_log2 > 2 && (q.chunks << pixels_log2) > 128u)
 				pixels_log2--;
 			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
-			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 128u && (pixels >> pixels_log2) < 49152u)
-				pixels_log2--;
-			if (pixels_log2 > 2 && (q.chunks << (pixels_log2 - 1u)) >= 64u && (pixels >> pixels_log2) < 24576u)
+			if (pixels_log2 > 2 && (pixels >> pixels_log2) < 49152u)
 				pixels_log2--;
 			if (const char* e = std::getenv("RT_HIP_PIXELS_LOG2")) // experiments only (tools/gpu_partition_times.py)
 				pixels_log2 = static_cast<uint32_t>(std::atoi(e));

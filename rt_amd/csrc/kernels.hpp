@@ -98,7 +98,10 @@ namespace rt_hip
 
 	struct device_counters
 	{
-		unsigned long long segments;
+		// path segments traced, as `segment_counters` partial sums (the host adds them up): every wave adds its count
+		// once, and 130 000 atomics on ONE address serialise at about 12 ns each — more than a small launch takes
+		static constexpr unsigned segment_counters = 64;
+		unsigned long long segments[segment_counters];
 		unsigned int next_tile; // head of the tile queue of the big-scene kernels; zeroed with the rest before every launch
 	};
 
