@@ -748,7 +748,9 @@ namespace rt_hip
 			// ---- one tile per wave: fold and write its pixels now (rolling tiles were folded as their last item came in) ----
 			if (!ROLLING)
 			{
-				__syncthreads();
+				// the slots are private to the wave: no workgroup barrier (the other three waves may still be tracing, and
+				// a wave that has written its pixels should free its slot), only ordering against this wave's own writes
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				fold_tile(slots, tile_x0, tile_y0);
 			}
 			add_segments(counters, st.segments);
