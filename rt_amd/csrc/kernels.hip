@@ -39,6 +39,9 @@
 #include <cstdlib>
 
 // waves per SIMD the kernel variants are compiled for (register budget = 512 / waves): measured, see render_queue
+#ifndef RT_HIP_WAVES_FEW
+#define RT_HIP_WAVES_FEW 7 // small kernel with 1..4 spheres
+#endif
 #ifndef RT_HIP_WAVES_MANY
 #define RT_HIP_WAVES_MANY 7 // small kernel with 5..8 spheres
 #endif
@@ -274,10 +277,11 @@ namespace rt_hip
 		// each tile, until all four waves are done.  NS == -2: `streamed` kernel — the resident loop reading the primitive
 		// table from HBM/L2 with wave-uniform scalar loads.
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
-		// launch bounds: 8 waves per SIMD (at most 64 VGPRs) where the kernel fits without scratch — the small kernel up to 4
-		// spheres; the scans are latency-bound chains and want the waves.  With 5..8 spheres in SGPRs and for the resident
-		// kernel 64 registers mean spills: 7 waves (72 VGPRs) are faster there (dielectric.toml, 7 spheres: 3.85 -> 3.54 ms;
-		// resident, 1000 spheres: -2 %; 6 waves no better).  The big-scene modes get the registers of 5 waves per SIMD.
+		// launch bounds: the scans are latency-bound chains and want many waves, but 8 per SIMD (64 VGPRs) is one too many:
+		// with 5..8 spheres in SGPRs and in the resident kernel 64 registers mean spills (dielectric.toml, 7 spheres:
+		// 3.85 -> 3.54 ms with 72 registers; resident, 1000 spheres: -2 %), and even the 3-sphere kernel, which fits 64
+		// without scratch, is 2 % faster compiled for 7 waves (3.12 -> 3.05 ms); 6 waves are slower everywhere.  The
+		// big-scene modes get the registers of 5 waves per SIMD.
 		//
 		// ROLLING TILES (NS < 0).  In a big scene a trip is one closest-hit scan over all primitives — the same cost for a
 		// wave with one lane holding a ray as for a wave with 64 — so what matters is that every lane holds a ray in every
@@ -296,7 +300,7 @@ namespace rt_hip
 		}
 
 		template <int NS, bool SM>
-		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : 8))) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
