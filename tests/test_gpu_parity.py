@@ -230,6 +230,26 @@ def test_random_scenes_are_bit_exact(tracer, case):
         assert stats["segments"] == want_stats["segments"]
 
 
+@pytest.mark.parametrize("case", range(6))
+def test_random_scenes_on_frames_with_more_pixel_tiles_than_persistent_waves(tracer, case):
+    """The big-scene kernels pull pixel tiles from a launch-wide queue, two open per wave: on a 1600x900 frame there are
+    11 250 tiles for at most 7168 waves, so buffers are re-opened while stragglers of the previous tile are in flight."""
+    rng = np.random.default_rng(7000 + case)
+    spheres, planes, materials, camera = random_scene(rng)
+    width, height = 1600, 900
+    spp, bounces = int(rng.integers(1, 4)), int(rng.integers(2, 12))
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
+    seed = int(rng.integers(0, 2**63))
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    for flags in (FORCE_TILED, FORCE_STREAMED):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
+        same = (got_rgb.view(np.uint32) == want_rgb.view(np.uint32)) | (np.isnan(got_rgb) & np.isnan(want_rgb))
+        assert same.all(), f"case {case} ({stats['kernel']}): {(~same).any(axis=-1).sum()} pixels differ"
+        assert np.array_equal(got_rgba, want_rgba)
+        assert stats["segments"] == want_stats["segments"]
+
+
 @pytest.mark.parametrize("flags", [0, FORCE_RESIDENT, FORCE_TILED], ids=["auto", "resident", "tiled"])
 @pytest.mark.parametrize("name,width,height,spp,seed", [("dielectric", 192, 108, 12, 21), ("dielectric", 64, 36, 40, 22), ("basic", 96, 54, 6, 23), ("planes", 96, 54, 6, 24)])
 def test_sm_material_table_is_bit_exact(tracer, planes_scene, name, width, height, spp, seed, flags):
