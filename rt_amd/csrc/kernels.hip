@@ -277,10 +277,11 @@ namespace rt_hip
 		// each tile, until all four waves are done.  NS == -2: `streamed` kernel — the resident loop reading the primitive
 		// table from HBM/L2 with wave-uniform scalar loads.
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
-		// launch bounds: the scans are latency-bound chains and want many waves, but 8 per SIMD (64 VGPRs) is one too many:
-		// with 5..8 spheres in SGPRs and in the resident kernel 64 registers mean spills (dielectric.toml, 7 spheres:
-		// 3.85 -> 3.54 ms with 72 registers; resident, 1000 spheres: -2 %), and even the 3-sphere kernel, which fits 64
-		// without scratch, is 2 % faster compiled for 7 waves (3.12 -> 3.05 ms); 6 waves are slower everywhere.  The
+		// launch bounds: compiled for 7 waves per SIMD.  That raises the compiler's budgets from 64 to 72 vector and from 72
+		// to 88 scalar registers.  With 5..8 spheres in SGPRs and in the resident kernel 64 VGPRs mean scratch
+		// (dielectric.toml, 7 spheres: 3.85 -> 3.54 ms with 72; resident, 1000 spheres: -2 %).  The 1..4 sphere kernels
+		// still fit 64 VGPRs — they keep running 8 waves — and use the extra scalar registers: the lane-mask bookkeeping of
+		// the divergent loop no longer spills to VGPR lanes (3.12 -> 3.05 ms).  6 waves are slower everywhere.  The
 		// big-scene modes get the registers of 5 waves per SIMD.
 		//
 		// ROLLING TILES (NS < 0).  In a big scene a trip is one closest-hit scan over all primitives — the same cost for a
