@@ -54,6 +54,8 @@ def lib() -> C.CDLL:
         l.oracle_render_mt19937.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(OracleStats)]
         l.oracle_random.restype = None
         l.oracle_random.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        l.oracle_stream_keys.restype = None
+        l.oracle_stream_keys.argtypes = [C.c_uint64, C.c_uint32] + [C.c_void_p] * 5
         l.oracle_closest_hit.restype = None
         l.oracle_closest_hit.argtypes = [C.POINTER(RtHipScene), C.c_uint32] + [C.c_void_p] * 6
         l.oracle_sqrt_div.restype = None
@@ -103,6 +105,18 @@ def random(seed: int, pixel: int, sample: int, n: int) -> np.ndarray:
     out = np.empty(n, dtype=np.float32)
     lib().oracle_random(seed, pixel, sample, n, out.ctypes.data)
     return out
+
+
+def stream_keys(seed: int, pixels, samples):
+    """(function key, stride, counter before the first draw) of the random stream of every (pixel, sample) pair."""
+    pixels = np.ascontiguousarray(pixels, dtype=np.uint32)
+    samples = np.ascontiguousarray(samples, dtype=np.uint32)
+    assert pixels.shape == samples.shape and pixels.ndim == 1
+    function_key = np.empty_like(pixels)
+    stride = np.empty_like(pixels)
+    counter = np.empty_like(pixels)
+    lib().oracle_stream_keys(seed, pixels.size, pixels.ctypes.data, samples.ctypes.data, function_key.ctypes.data, stride.ctypes.data, counter.ctypes.data)
+    return function_key, stride, counter
 
 
 def closest_hit(scene: RtHipScene, origins, directions):

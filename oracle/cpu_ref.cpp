@@ -14,11 +14,12 @@
 //   pixel addressing ............ src/image.hpp:143-159
 //
 // The vector/ray arithmetic itself lives in marzer/muu (absent offline).  The formulas chosen for it are
-// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v1") is this project's own and is what
+// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v2": v1's floating-point rules + per-pixel keyed
+// random streams) is this project's own and is what
 // the GPU kernels reproduce bit for bit.  The reference is built with -ffast-math -ffp-contract=fast
 // (meson.build:153-160), so it defines no operation order of its own.
 //
-// Arithmetic contract v1 — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
+// Arithmetic contract (v1 and v2) — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
 // no contraction or reassociation except the fmaf() written out here; sqrtf and '/' are correctly rounded:
 //   dot(a,b)          = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
 //   normalize(v)      = v * (1.0f / sqrtf(dot(v,v)))            (one division, three products)
@@ -81,14 +82,20 @@ namespace
 
 	// ---- random streams -------------------------------------------------------------------------------------
 	// The reference draws from a thread_local std::mt19937 seeded by std::random_device (src/random.cpp:9-26):
-	// not reproducible, and tied to which host thread ran the pixel.  Replaced by a counter-based stream keyed by
-	// (seed, GLOBAL pixel index, sample index); draw k of a sample is a pure function of those four numbers.
-	//   hash32  = the "lowbias32" integer finaliser (xorshift-multiply, two rounds)
-	//   frame   = hash32(lo32(seed) ^ hash32(hi32(seed) ^ 0x9E3779B9))
-	//   pixel   = hash32(frame ^ pixel_index)
-	//   counter = pixel + sample_index * (0x9E3779B9 * 4096)            (mod 2^32; 4096 draws reserved per sample)
-	//   draw    : counter += 0x9E3779B9;  u = float(hash32(counter) >> 8) * 2^-24      in [0, 1)
-	// i.e. all draws of a pixel are hash32 of one arithmetic progression (a Weyl sequence) starting at a hashed offset.
+	// not reproducible, and tied to which host thread ran the pixel.  Replaced by counter-based streams in which
+	// draw k of a sample is a pure function of (seed, GLOBAL pixel index, sample index, k).  Contract v2: every pixel
+	// of a frame draws through its OWN keyed hash function, walked along its OWN arithmetic progression of counters
+	// (64 bits of key per pixel), as the reference's generators are independent of one another:
+	//   hash32   = the "lowbias32" integer finaliser (xorshift-multiply, two rounds)
+	//   (fa, fb) = low and high half of mix64(seed), mix64 = the splitmix64 finaliser (a bijection of 64-bit words)
+	//   k        = hash32(pixel_index ^ fa)          function key — a bijection of the pixel index: never shared in a frame
+	//   stride   = hash32(k ^ fb) | 1                counter stride (odd)
+	//   counter  = stride * (sample_index * 4096)    before the first draw of a sample (mod 2^32; 4096 draws reserved per sample)
+	//   draw     : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
+	//              x *= 0x846ca68b;  x ^= x >> 16;  u = float(x >> 8) * 2^-24      in [0, 1)
+	// Two pixels with different strides evaluate their (different) functions at a common counter only at isolated
+	// draws, never along a run.  (Contract v1 drew every pixel from ONE shared hash32 sequence at a hashed offset; a
+	// 1920x1080x256 frame draws 3.6e9 numbers, so most sample windows overlapped another pixel's and some were identical.)
 	inline uint32_t hash32(uint32_t x)
 	{
 		x ^= x >> 16;
@@ -99,24 +106,43 @@ namespace
 		return x;
 	}
 
-	inline uint32_t frame_key(uint64_t seed)
+	struct frame_keys
 	{
-		return hash32(static_cast<uint32_t>(seed) ^ hash32(static_cast<uint32_t>(seed >> 32) ^ 0x9E3779B9u));
+		uint32_t a, b;
+	};
+
+	inline frame_keys make_frame_keys(uint64_t seed)
+	{
+		uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z ^= z >> 31;
+		return { static_cast<uint32_t>(z), static_cast<uint32_t>(z >> 32) };
 	}
 
 	struct random_stream
 	{
+		uint32_t function_key;
+		uint32_t stride;
 		uint32_t counter;
 
-		random_stream(uint32_t frame, uint32_t pixel_index, uint32_t sample_index)
-			: counter{ hash32(frame ^ pixel_index) + sample_index * (0x9E3779B9u * 4096u) }
+		random_stream(frame_keys frame, uint32_t pixel_index, uint32_t sample_index)
+			: function_key{ hash32(pixel_index ^ frame.a) },
+			  stride{ hash32(function_key ^ frame.b) | 1u },
+			  counter{ stride * (sample_index << 12) }
 		{}
 
 		// random<float>(), src/random.hpp:12-17 / src/random.cpp:20-26: uniform in [0, 1)
 		float next()
 		{
-			counter += 0x9E3779B9u;
-			return static_cast<float>(hash32(counter) >> 8) * 0x1.0p-24f;
+			counter += stride;
+			uint32_t x = counter;
+			x ^= x >> 16;
+			x = x * 0x7feb352du + function_key;
+			x ^= x >> 15;
+			x *= 0x846ca68bu;
+			x ^= x >> 16;
+			return static_cast<float>(x >> 8) * 0x1.0p-24f;
 		}
 	};
 
@@ -150,7 +176,7 @@ namespace
 		std::vector<material> materials;
 		uint32_t width, height;
 		float sx, sy; // 2 / W, 2 / H
-		uint32_t frame_key;
+		frame_keys keys;
 		int trace_order;
 		bool sm_materials;
 	};
@@ -163,7 +189,7 @@ namespace
 		f.height = h;
 		f.sx = 2.0f / static_cast<float>(w);
 		f.sy = 2.0f / static_cast<float>(h);
-		f.frame_key = frame_key(seed);
+		f.keys = make_frame_keys(seed);
 		f.trace_order = mode & ORACLE_TRACE_RECURSIVE;
 		f.sm_materials = (mode & ORACLE_MATERIALS_SM) != 0;
 		f.materials.resize(s->n_materials);
@@ -514,7 +540,7 @@ namespace
 		vec3 chunk = { 0, 0, 0 };
 		for (uint32_t i = 0, e = s.samples_per_pixel; i < e; i++)
 		{
-			random_stream rng{ f.frame_key, pixel_index, i };
+			random_stream rng{ f.keys, pixel_index, i };
 			float jx = 0.5f, jy = 0.5f; // sample 0 goes through the pixel centre (:189)
 			if (i)
 			{
@@ -686,9 +712,21 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 
 extern "C" void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
 {
-	random_stream rng{ frame_key(seed), pixel, sample };
+	random_stream rng{ make_frame_keys(seed), pixel, sample };
 	for (uint32_t i = 0; i < n; i++)
 		out[i] = rng.next();
+}
+
+extern "C" void oracle_stream_keys(uint64_t seed, uint32_t n, const uint32_t* pixels, const uint32_t* samples, uint32_t* out_function_key, uint32_t* out_stride, uint32_t* out_counter)
+{
+	const frame_keys keys = make_frame_keys(seed);
+	for (uint32_t i = 0; i < n; i++)
+	{
+		const random_stream rng{ keys, pixels[i], samples[i] };
+		out_function_key[i] = rng.function_key;
+		out_stride[i] = rng.stride;
+		out_counter[i] = rng.counter;
+	}
 }
 
 extern "C" void oracle_closest_hit(const rt_hip_scene* scene,

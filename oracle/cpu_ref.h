@@ -69,6 +69,8 @@ int oracle_render_mt19937(const rt_hip_scene* scene,
 
 /* Leaf functions, for known-answer tests and device KATs. */
 void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
+/* state of the random stream of (pixel, sample) before its first draw: the pixel's function key and stride, and the counter */
+void oracle_stream_keys(uint64_t seed, uint32_t n, const uint32_t* pixels, const uint32_t* samples, uint32_t* out_function_key, uint32_t* out_stride, uint32_t* out_counter);
 void oracle_closest_hit(const rt_hip_scene* scene,
 						uint32_t n,
 						const float* origins,

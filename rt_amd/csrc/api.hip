@@ -540,7 +540,9 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		{}
 	f.samples_per_pixel = ctx->samples_per_pixel;
 	f.max_bounces = ctx->max_bounces;
-	f.frame_key = frame_key(seed);
+	const frame_keys keys = make_frame_keys(seed);
+	f.frame_key_a = keys.a;
+	f.frame_key_b = keys.b;
 	f.sx = 2.0f / static_cast<float>(width);
 	f.neg_sy = -(2.0f / static_cast<float>(height));
 	const float* M = ctx->inverse_view_projection;
@@ -692,7 +694,8 @@ extern "C" rt_hip_status rt_hip_kat_random(rt_hip_ctx* ctx, uint64_t seed, uint3
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_kat_random: invalid argument");
 	RT_HIP_TRY(hipSetDevice(ctx->device));
 	RT_HIP_TRY(ctx->kat_out.reserve(static_cast<size_t>(n) * sizeof(float)));
-	launch_kat_random(frame_key(seed), pixel, sample, n, ctx->kat_out.as<float>(), nullptr);
+	const frame_keys keys = make_frame_keys(seed);
+	launch_kat_random(keys.a, keys.b, pixel, sample, n, ctx->kat_out.as<float>(), nullptr);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipMemcpy(out, ctx->kat_out.ptr, static_cast<size_t>(n) * sizeof(float), hipMemcpyDeviceToHost));
 	return ok();

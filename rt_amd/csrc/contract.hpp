@@ -1,4 +1,5 @@
-// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v1".
+// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v2"
+// (v2 = v1's floating-point rules with per-pixel keyed random streams).
 //
 // Every function here is the gfx950 counterpart of a reference function on the mg_ray_tracer path and produces
 // bit-identical binary32 results to the CPU oracle:
@@ -155,6 +156,22 @@ namespace rt_hip
 	__device__ __forceinline__ vec3 ray_at(vec3 o, vec3 d, float t) { return { fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z) }; }
 
 	// ---- random streams (replaces src/random.cpp:9-26) ------------------------------------
+	// Contract v2: every pixel of a frame draws through its OWN keyed hash function, evaluated along its OWN arithmetic
+	// progression of counters — 64 bits of key per (frame, pixel), as the reference's generators are independent of one
+	// another (src/random.cpp:9-13):
+	//   (fa, fb)  = the two halves of mix64(seed)                       (bijective: distinct seeds, distinct frame keys)
+	//   k         = hash32(pixel ^ fa)            the pixel's FUNCTION key: a bijection of the pixel index, so no two
+	//                                             pixels of a frame ever draw through the same function
+	//   stride    = hash32(k ^ fb) | 1            the pixel's counter stride (odd: m -> stride * m is a bijection)
+	//   counter   = stride * (sample * 4096)      before the first draw of a sample: 4096 draws reserved per sample
+	//   draw      : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
+	//               x *= 0x846ca68b;  x ^= x >> 16;  u = (x >> 8) * 2^-24
+	// i.e. the lowbias32 finaliser with the pixel's key added between its two rounds, walked with the pixel's stride.
+	// For a fixed key the map counter -> x is a bijection of 32-bit words.  The 2^32 counter values are shared by all
+	// pixels (a 4K x 256 spp frame makes 1.5e10 draws), but two pixels with different strides meet only at isolated
+	// counters, never along a run of consecutive draws, and what they compute there goes through different functions.
+	// (Contract v1 drew every pixel from ONE shared sequence at a hashed offset: at 1920x1080x256 samples most sample
+	// windows overlapped another pixel's, and 3e7 samples repeated another sample's whole stream.)
 	__device__ __host__ __forceinline__ uint32_t hash32(uint32_t x)
 	{
 		x ^= x >> 16;
@@ -165,35 +182,58 @@ namespace rt_hip
 		return x;
 	}
 
-	__host__ inline uint32_t frame_key(uint64_t seed)
+	struct frame_keys
 	{
-		return hash32(static_cast<uint32_t>(seed) ^ hash32(static_cast<uint32_t>(seed >> 32) ^ 0x9E3779B9u));
+		uint32_t a, b;
+	};
+
+	__host__ inline frame_keys make_frame_keys(uint64_t seed) // the splitmix64 finaliser: a bijection of 64-bit words
+	{
+		uint64_t z = seed + 0x9E3779B97F4A7C15ull;
+		z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+		z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+		z ^= z >> 31;
+		return { static_cast<uint32_t>(z), static_cast<uint32_t>(z >> 32) };
 	}
 
-	__device__ __forceinline__ uint32_t pixel_key(uint32_t frame, uint32_t pixel_index) { return hash32(frame ^ pixel_index); }
+	__device__ __forceinline__ uint32_t pixel_function_key(uint32_t frame_a, uint32_t pixel_index) { return hash32(pixel_index ^ frame_a); }
+	__device__ __forceinline__ uint32_t pixel_stride(uint32_t frame_b, uint32_t function_key) { return hash32(function_key ^ frame_b) | 1u; }
 	// stream position before the first draw of sample `sample_index`: 4096 draws are reserved per sample
-	constexpr uint32_t draw_stride = 0x9E3779B9u;
-	constexpr uint32_t sample_stride = draw_stride * 4096u; // mod 2^32
-	__device__ __forceinline__ uint32_t sample_counter(uint32_t pixel, uint32_t sample_index) { return pixel + sample_index * sample_stride; }
+	constexpr uint32_t draws_per_sample_log2 = 12;
+	__device__ __forceinline__ uint32_t sample_counter(uint32_t stride, uint32_t sample_index) { return stride * (sample_index << draws_per_sample_log2); }
+
+	__device__ __forceinline__ uint32_t keyed_hash32(uint32_t x, uint32_t function_key)
+	{
+		x ^= x >> 16;
+		x = x * 0x7feb352du + function_key;
+		x ^= x >> 15;
+		x *= 0x846ca68bu;
+		x ^= x >> 16;
+		return x;
+	}
 
 	// random<float>(), src/random.hpp:12-17: uniform in [0, 1), as the integer k of u = k * 2^-24 (0 <= k < 2^24, exact)
 	constexpr float random_scale = 0x1.0p-24f;
-	__device__ __forceinline__ float next_random_numerator(uint32_t& counter)
+	struct stream_keys
 	{
-		counter += draw_stride;
-		return static_cast<float>(hash32(counter) >> 8);
+		uint32_t function_key, stride;
+	};
+	__device__ __forceinline__ float next_random_numerator(uint32_t& counter, stream_keys keys)
+	{
+		counter += keys.stride;
+		return static_cast<float>(keyed_hash32(counter, keys.function_key) >> 8);
 	}
-	__device__ __forceinline__ float next_random(uint32_t& counter) { return next_random_numerator(counter) * random_scale; }
+	__device__ __forceinline__ float next_random(uint32_t& counter, stream_keys keys) { return next_random_numerator(counter, keys) * random_scale; }
 
 	// random_unit_vector(), src/random.hpp:57-66 (positive octant only)
-	__device__ __forceinline__ vec3 random_unit_vector(uint32_t& counter)
+	__device__ __forceinline__ vec3 random_unit_vector(uint32_t& counter, stream_keys keys)
 	{
 		float x, y, z;
 		do
 		{
-			x = next_random(counter);
-			y = next_random(counter);
-			z = next_random(counter);
+			x = next_random(counter, keys);
+			y = next_random(counter, keys);
+			z = next_random(counter, keys);
 		}
 		while (x == 0.0f && y == 0.0f && z == 0.0f);
 		return normalize_unit_cube_draw({ x, y, z });

@@ -198,7 +198,7 @@ namespace rt_hip
 			vec3 throughput;	// product of attenuations so far (trace unrolled front to back)
 			vec3 chunk_sum;		// running sum of the chunk of samples in flight (:186,193)
 			float fx, fy;		// pixel coordinates as floats
-			uint32_t pixel_key; // random stream key of the pixel
+			stream_keys keys;	// random streams of the pixel (contract.hpp): the key of its hash function and its counter stride
 			uint32_t counter;	// random stream position
 			uint32_t sample;	// index of the sample in flight
 			uint32_t sample_end; // one past the last sample of the chunk in flight
@@ -550,7 +550,8 @@ namespace rt_hip
 						const uint32_t gy = global_row(ly, p);
 						st.fx = static_cast<float>(lx);
 						st.fy = static_cast<float>(gy);
-						st.pixel_key = pixel_key(p.frame_key, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+						st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+						st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
 						st.sample = chunk * sample_chunk;
 						st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
 						mode = lane_restart;
@@ -641,11 +642,11 @@ namespace rt_hip
 				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
 				{
 					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
-					uint32_t counter = restart ? sample_counter(st.pixel_key, st.sample) : st.counter;
+					uint32_t counter = restart ? sample_counter(st.keys.stride, st.sample) : st.counter;
 					const uint32_t counter_at_start = counter;
 					// (as numerators k of u = k * 2^-24: the scaling folds into the jitter's fma and cancels in the unit vector)
-					float d0 = next_random_numerator(counter);
-					float d1 = next_random_numerator(counter);
+					float d0 = next_random_numerator(counter, st.keys);
+					float d1 = next_random_numerator(counter, st.keys);
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
 					bool absorbed = false;
 					bool unit_length = false; // `toward` is used as it is (sm's dielectric_scatter does not normalise)
@@ -679,7 +680,7 @@ namespace rt_hip
 							const double x5 = (x2 * x2) * x;
 							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
 						}
-						counter = counter_at_start + draw_stride; // only d0 was consumed
+						counter = counter_at_start + st.keys.stride; // only d0 was consumed
 						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
 						unit_length = true;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
@@ -688,12 +689,12 @@ namespace rt_hip
 					else if (shade)
 					{
 						const bool metal = scatter_kind == scatter_metal;
-						float d2 = next_random_numerator(counter);
+						float d2 = next_random_numerator(counter, st.keys);
 						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
 						{
-							d0 = next_random_numerator(counter);
-							d1 = next_random_numerator(counter);
-							d2 = next_random_numerator(counter);
+							d0 = next_random_numerator(counter, st.keys);
+							d1 = next_random_numerator(counter, st.keys);
+							d2 = next_random_numerator(counter, st.keys);
 						}
 						const vec3 u = normalize_unit_cube_numerators({ d0, d1, d2 });
 						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
@@ -896,13 +897,16 @@ namespace rt_hip
 		}
 
 		// ---- known-answer kernels -----------------------------------------------------------------------------------
-		__global__ void kat_random(uint32_t frame, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
+		__global__ void kat_random(frame_keys frame, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
 		{
 			if (blockIdx.x || threadIdx.x)
 				return;
-			uint32_t counter = sample_counter(pixel_key(frame, pixel), sample);
+			stream_keys keys;
+			keys.function_key = pixel_function_key(frame.a, pixel);
+			keys.stride = pixel_stride(frame.b, keys.function_key);
+			uint32_t counter = sample_counter(keys.stride, sample);
 			for (uint32_t i = 0; i < n; i++)
-				out[i] = next_random(counter);
+				out[i] = next_random(counter, keys);
 		}
 
 		__global__ __launch_bounds__(block_threads) void kat_closest_hit(const device_scene s,
@@ -1189,9 +1193,9 @@ namespace rt_hip
 		hipLaunchKernelGGL(assemble_stripes, grid, dim3(block_threads), 0, stream, width, height, world, stripe_rows, padded_local_rows, d_gathered, d_frame);
 	}
 
-	void launch_kat_random(uint32_t frame, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream)
+	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream)
 	{
-		hipLaunchKernelGGL(kat_random, dim3(1), dim3(64), 0, stream, frame, pixel, sample, n, d_out);
+		hipLaunchKernelGGL(kat_random, dim3(1), dim3(64), 0, stream, frame_keys{ frame_key_a, frame_key_b }, pixel, sample, n, d_out);
 	}
 
 	void launch_kat_closest_hit(const device_scene& scene,

@@ -58,7 +58,7 @@ namespace rt_hip
 		uint32_t rank, world, stripe_rows; // rt_hip_partition
 		uint32_t stripe_shift;			   // log2(stripe_rows) if that is a power of two, else 0xFFFFFFFF (general division)
 		uint32_t samples_per_pixel, max_bounces;
-		uint32_t frame_key;				   // hash of the 64-bit seed
+		uint32_t frame_key_a, frame_key_b;  // the two halves of the mixed 64-bit seed (contract.hpp, random streams)
 		float sx, neg_sy;				   // 2/W and -(2/H): ndc = (fma(px, sx, -1), fma(py, neg_sy, 1))
 		// inverse view-projection, pre-split for depth 0 / depth 1 (camera.hpp:42-48):
 		// row_r(depth) = fma(mx[r], ndc.x, fma(my[r], ndc.y, k[r])),  k_near[r] = fma(M[r][2], 0, M[r][3]),
@@ -134,7 +134,7 @@ namespace rt_hip
 						 uint32_t* d_frame,
 						 hipStream_t stream);
 
-	void launch_kat_random(uint32_t frame_key, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream);
+	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream);
 	void launch_kat_closest_hit(const device_scene& scene,
 								uint32_t n,
 								const float* d_origins,

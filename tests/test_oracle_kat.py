@@ -232,6 +232,138 @@ def test_first_draws_across_pixels_are_uniform():
     assert ((counts - 1250) ** 2 / 1250).sum() < 50
 
 
+# ---- contract v2: per-pixel keyed streams --------------------------------------------------------------------------------
+M32 = np.uint64(0xFFFFFFFF)
+
+
+def _hash32(x):
+    """lowbias32 on uint64 arrays holding 32-bit words (an implementation independent of the oracle's C++)."""
+    x = x & M32
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x7FEB352D)) & M32
+    x ^= x >> np.uint64(15)
+    x = (x * np.uint64(0x846CA68B)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def _frame_keys(seed):
+    m = (1 << 64) - 1
+    z = (seed + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    z ^= z >> 31
+    return z & 0xFFFFFFFF, z >> 32
+
+
+def _stream_start(seed, pixels, samples):
+    """(function key, stride, counter before the first draw) per contract v2, in numpy."""
+    fa, fb = _frame_keys(seed)
+    key = _hash32(pixels.astype(np.uint64) ^ np.uint64(fa))
+    stride = _hash32(key ^ np.uint64(fb)) | np.uint64(1)
+    counter = (stride * (samples.astype(np.uint64) << np.uint64(12))) & M32
+    return key, stride, counter
+
+
+def _draws(key, stride, counter, n):
+    """first n draws of the streams starting at (key, stride, counter): float32[len(key), n]"""
+    out = np.empty((len(key), n), dtype=np.float32)
+    c = counter.copy()
+    for j in range(n):
+        c = (c + stride) & M32
+        x = c ^ (c >> np.uint64(16))
+        x = (x * np.uint64(0x7FEB352D) + key) & M32
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & M32
+        x ^= x >> np.uint64(16)
+        out[:, j] = (x >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)
+    return out
+
+
+def test_stream_contract_matches_an_independent_numpy_implementation():
+    rng = np.random.default_rng(3)
+    pixels = rng.integers(0, 3840 * 2160, 200, dtype=np.uint32)
+    samples = rng.integers(0, 1000, 200, dtype=np.uint32)
+    for seed in (0, 1, 0x0123456789ABCDEF, (1 << 64) - 1):
+        key, stride, counter = _stream_start(seed, pixels, samples)
+        got = oracle.stream_keys(seed, pixels, samples)
+        for mine, theirs in zip((key, stride, counter), got):
+            assert np.array_equal(theirs, mine.astype(np.uint32))
+        want = _draws(key, stride, counter, 12)
+        for i in range(0, 200, 17):
+            assert np.array_equal(oracle.random(seed, int(pixels[i]), int(samples[i]), 12), want[i])
+
+
+def test_no_two_samples_of_a_1080p_frame_share_or_overlap_a_stream():
+    """Round-1 finding: under contract v1 a 1920x1080x16 frame had 120 201 (pixel, sample) pairs
+    with IDENTICAL streams and 1.6 M sample windows starting within 7 draws of another.  Under v2 a stream is the
+    triple (function key, stride, counter): the function key is a bijection of the pixel index, so two pixels never
+    draw through the same function, and the samples of one pixel occupy disjoint windows of its own progression."""
+    width, height, spp, seed = 1920, 1080, 16, 1
+    pixels = np.repeat(np.arange(width * height, dtype=np.uint32), spp)
+    samples = np.tile(np.arange(spp, dtype=np.uint32), width * height)
+    key, stride, counter = oracle.stream_keys(seed, pixels, samples)
+    # 1. the function key is injective in the pixel index; the stride is odd
+    per_pixel = key[::spp]
+    assert np.all(key.reshape(-1, spp) == per_pixel[:, None])
+    assert len(np.unique(per_pixel)) == width * height
+    assert np.all(stride & 1 == 1)
+    # 2. no two (pixel, sample) pairs start in the same state — the measurement that found 120 201 duplicates in v1
+    state = (key.astype(np.uint64) << np.uint64(32)) | counter.astype(np.uint64)
+    state.sort()
+    assert np.all(state[1:] != state[:-1])
+    # 3. shifted overlaps: a stream can only run into another one that shares its function key, i.e. its pixel; within
+    #    a pixel, sample s occupies positions [4096 s + 1, 4096 (s + 1)] of the pixel's progression counter = stride * m
+    #    (the stride is odd, so m -> counter is a bijection of 32-bit words: division is exact)
+    inverse = np.array([pow(int(v), -1, 1 << 32) for v in stride[::spp][:5000]], dtype=np.uint64)
+    position = (counter.reshape(-1, spp)[:5000].astype(np.uint64) * inverse[:, None]) & M32
+    assert np.array_equal(position, np.broadcast_to(np.arange(spp, dtype=np.uint64) * np.uint64(4096), position.shape))
+    # 4. runs of common counters between two pixels need equal strides.  A few pixel pairs of a frame do share a stride
+    #    (32-bit hashes of 2 M pixels); their function keys must then be unrelated — at least a few bits apart
+    strides = stride[::spp]
+    order = np.argsort(strides, kind="stable")
+    same = np.nonzero(strides[order][1:] == strides[order][:-1])[0]
+    assert len(same) < 3000  # ~ (2 M)^2 / 2 / 2^31 = 1000 expected
+    distance = [bin(int(per_pixel[order[i]]) ^ int(per_pixel[order[i + 1]])).count("1") for i in same]
+    assert min(distance, default=32) >= 4
+
+
+def test_pixels_reading_the_same_counters_get_unrelated_numbers():
+    """The 2^32 counter values are shared by all pixels.  Two pixels that do walk the same counters (equal strides: about a
+    thousand pairs in a 1080p frame) must still see unrelated numbers, because their functions differ."""
+    n = 4096
+    keys = _hash32(np.arange(2000, dtype=np.uint64) ^ np.uint64(0xDEADBEEF))  # function keys of 2000 neighbouring pixels
+    stride = np.full(2000, 0x9E3779B9, dtype=np.uint64)
+    draws = _draws(keys, stride, np.zeros(2000, dtype=np.uint64), n)  # every row walks the SAME counters
+    assert abs(draws.mean() - 0.5) < 0.002
+    a, b = draws[::2], draws[1::2]
+    corr = [np.corrcoef(x, y)[0, 1] for x, y in zip(a, b)]
+    assert np.abs(corr).max() < 5.5 / np.sqrt(n) and abs(np.mean(corr)) < 3.0 / np.sqrt(n * len(corr))
+    # a key that merely rotated the output by a constant would pass the correlation test: the difference must be uniform
+    for row in ((a - b) % 1.0)[:200]:
+        counts, _ = np.histogram(row, bins=16, range=(0, 1))
+        assert ((counts - n / 16) ** 2 / (n / 16)).sum() < 70  # 15 dof, p ~ 1e-8
+
+
+def test_neighbouring_pixels_have_unrelated_streams():
+    rng = np.random.default_rng(5)
+    n = 4096
+    pixels = np.arange(1000, 1000 + 64, dtype=np.uint32)
+    key, stride, counter = _stream_start(1, pixels, np.full(64, 3, dtype=np.uint32))
+    draws = _draws(key, stride, counter, n)
+    corr = np.corrcoef(draws)
+    np.fill_diagonal(corr, 0.0)
+    assert np.abs(corr).max() < 5.5 / np.sqrt(n)
+    # lagged: the jitter draws of one pixel against the scatter draws of the next
+    for lag in (1, 2, 3):
+        assert abs(np.corrcoef(draws[:-1, lag:].ravel(), draws[1:, :-lag].ravel())[0, 1]) < 4.0 / np.sqrt(63 * (n - lag))
+
+
+def test_seeds_that_differ_only_in_the_high_half_give_different_frames():
+    u = [oracle.random(seed, 5, 1, 64) for seed in (7, 7 | (1 << 32), 7 | (1 << 63))]
+    assert not np.array_equal(u[0], u[1]) and not np.array_equal(u[0], u[2]) and not np.array_equal(u[1], u[2])
+
+
 # ---- whole-frame behaviour -----------------------------------------------------------------------------------------------
 def test_sample_zero_goes_through_the_pixel_centre_and_is_seed_independent():
     # spp = 1, max_bounces = 1: no random draw is consumed at all (mg_ray_tracer.cpp:189)
