@@ -19,11 +19,15 @@ all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so rt_amd/bin/rt_headless oracl
 
 $(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -L/opt/rocm/lib -lrccl
 
 $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC)
+
+# experiment builds for tools/gpu_ab.py: make variant NAME=x DEFS="-DRT_HIP_SOMETHING=1" -> rt_amd/lib/librt_hip_x.so
+variant:
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(HIP_SRC) -L/opt/rocm/lib -lrccl
 
 # windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
 HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
@@ -38,4 +42,4 @@ clean:
 	rm -f $(LIBDIR)/*.so rt_amd/bin/rt_headless
 	$(MAKE) -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean variant

@@ -4,16 +4,22 @@ scenes/basic.toml (BASELINE.json `metric`), on N MI355X of one node.
 
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W              # one process per GPU (what the driver launches)
+    python bench.py --gpus N --steps K --warmup W            # not under torchrun: ONE process drives all N GPUs through
+                                                            # rt_hip_create_multi — the form the reference's blocking
+                                                            # render() can use (--same-device rehearses it on one GPU)
 
-A "step" is one full frame: every rank renders its row stripes with the HIP kernels (scene already resident in
-HBM), the stripes are gathered to rank 0 over RCCL and de-interleaved there (N = 1: kernel only).  The frame is
-fixed as N grows, so scaling is STRONG.  Rank 0 prints ONE JSON line.
+A "step" is one whole `render(scene, back_buffer)` as the reference makes it: host scene
+columns in, finished frame in the caller's HOST buffer out, ONE frame at a time — scene fingerprint check (the columns
+were uploaded during warm-up and are not re-sent while unchanged), kernel(s), for N > 1 the RCCL gather to rank 0 and the
+de-interleave, and the device-to-host transfer of the frame.  `value` is that drop-in rate; the kernel-only rate (scene
+resident, frame left in HBM) is carried beside it as `kernel_only`.  The frame is fixed as N grows: scaling is STRONG.
 
-The `roofline` object prices the render kernel against the FP32 vector-ALU peak — the bound SURVEY.md §8d
-identifies for this path (a 3-sphere scene is ~100 bytes; the only compulsory HBM traffic is the 4 B/pixel frame) —
-and carries the HBM figures next to it.  `cpu_baseline` times the reference-faithful CPU model (oracle/, mt19937
-mode) on a bounded sample of the same workload on this box's host cores.
+The `roofline` object prices the render kernel against the FP32 vector-ALU peak — the bound SURVEY.md §8d identifies for
+this path (a 3-sphere scene is ~100 bytes; the only compulsory HBM traffic is the 4 B/pixel frame) — from the kernel's
+duration measured with HIP events on its launch stream (recorded by the module around every launch of the timed region
+and read back through rt_hip_stats), and carries the HBM figures next to it.  `cpu_baseline` times the
+reference-faithful CPU model (oracle/, mt19937 mode) on a bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
 
@@ -34,6 +40,16 @@ HBM_PEAK_GBPS = 8000.0  # same guide, HBM3E spec
 def algorithmic_flops(samples: int, segments: int, n_spheres: int, n_planes: int) -> float:
     """S*70 + segments*(22*N_s + 16*N_p + 60)."""
     return samples * 70.0 + segments * (22.0 * n_spheres + 16.0 * n_planes + 60.0)
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown CPU"
 
 
 def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float) -> dict:
@@ -57,7 +73,9 @@ def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{scene_name}.toml {width}x{height} at {spp} spp (of the workload's spp), mt19937 model, -O3 -mavx2 -mfma -ffast-math, {stats['seconds']:.1f} s",
+        "sample": f"{scene_name} {width}x{height} at {spp} spp (of the workload's spp), {stats['seconds']:.1f} s on {cores} threads of {cpu_model()}; "
+        "CPU restatement of mg_ray_tracer (thread_local mt19937, recursion, AoS scan), g++ -O3 -mavx2 -mfma -ffast-math -ffp-contract=fast "
+        "(-march=native is not used: the .so is built on another host)",
     }
 
 
@@ -74,11 +92,14 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
     ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
+    ap.add_argument("--fast", action="store_true", help="RT_HIP_FLAG_FAST: the tolerance-bound arithmetic (raw v_rsq/v_rcp), a second bench line; never the parity contract")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--frames-in-flight", type=int, default=0, help="1: one frame at a time; 2: consecutive frames alternate between two streams; 0 = 1 on one GPU, 2 on several")
+    ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
+    ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
 
@@ -88,8 +109,10 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    single_process = world == 1
+    if not single_process and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    n_gpus = args.gpus
 
     device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
@@ -100,18 +123,12 @@ def main() -> None:
         else:
             dist.init_process_group("gloo")
 
-    in_flight = args.frames_in_flight or (1 if world == 1 else 2)
-    tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]  # fails loudly without librt_hip.so or a gfx950 device
-    tracer = tracers[0]
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
     pod = scene.describe(args.width, args.height)
-    for t in tracers:
-        t.upload(pod)  # inputs resident in HBM before the timed region
     flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else 0)
-    frame = distributed.DistributedFrame(tracers, args.width, args.height)
-
-    def step():
-        return frame.render(seed=args.seed, flags=flags)
+    if args.fast:
+        flags |= capi.RT_HIP_FLAG_FAST
+    samples_total = args.width * args.height * args.spp
 
     def fence():
         torch.cuda.synchronize()
@@ -119,56 +136,98 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    kernel_ms_sum = 0.0
+    readback_ms_sum = 0.0
+    kernel_only = None
+    if single_process:
+        # ---- ONE process: rt_hip_render, the drop-in call, on one context (1 GPU) or one multi-GPU context ----
+        if n_gpus == 1:
+            tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
+            transport = None
+        elif args.same_device:
+            tracer = rt_amd.HipRayTracer(devices=[device] * n_gpus, peer_copy=True)
+            transport = "peer copies on one device (rehearsal)"
+        else:
+            tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)))
+            transport = "RCCL: ncclCommInitAll + one ncclGather to device 0"
+        back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
+        render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
 
-    # kernel duration: HIP events on the launch stream around every render launch of the timed region
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ends = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    launch = {"i": 0}
+        def step():
+            return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
 
-    def timed(real_render_device):
-        def timed_render_device(*a, **k):
-            i = launch["i"]
-            stream = torch.cuda.current_stream()  # DistributedFrame launches on the current stream of its slot
-            starts[i].record(stream)
-            real_render_device(*a, **k)
-            ends[i].record(stream)
-            launch["i"] = i + 1
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats = step()  # blocking: returns with the frame in back_buffer
+            # HIP events on the launch stream around this step's kernel (several GPUs: member 0's launch, its share of the frame)
+            kernel_ms_sum += stats["render_ms"] if n_gpus == 1 else tracer.member_stats(0)["render_ms"]
+            readback_ms_sum += stats["readback_ms"]
+        fence()
+        elapsed = time.perf_counter() - t0
+        member0 = tracer.member_stats(0) if n_gpus > 1 else stats
 
-        return timed_render_device
+        if n_gpus == 1:
+            # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
+            frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
+            torch.cuda.synchronize()
+            per_frame = (time.perf_counter() - t1) / args.steps
+            kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
+    else:
+        # ---- one process per GPU (torchrun): stripes -> gather over RCCL -> assemble -> host frame on rank 0 ----
+        in_flight = max(1, args.frames_in_flight)
+        tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
+        tracer = tracers[0]
+        for t in tracers:
+            t.upload(pod)
+        frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
+        host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
+        transport = "torch.distributed gather (backend nccl = RCCL)" if args.backend == "nccl" else "gloo rehearsal"
 
-    originals = [t.render_device for t in tracers]
-    for t, original in zip(tracers, originals):
-        t.render_device = timed(original)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    for t, original in zip(tracers, originals):
-        t.render_device = original
+        def step():
+            frame = frame_maker.render(seed=args.seed, flags=flags)
+            if frame is not None:
+                host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
+            if in_flight == 1:
+                torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
+            return tracers[(frame_maker.frames - 1) % in_flight]
 
-    if world > 1:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            used = step()
+            if in_flight == 1:
+                kernel_ms_sum += used.stats()["render_ms"]
+        fence()
+        elapsed = time.perf_counter() - t0
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    kernel_ms = sum(s.elapsed_time(e) for s, e in zip(starts, ends)) / args.steps
-    stats = tracers[(args.steps - 1) % in_flight].stats()  # counters of this rank's last launch
+        member0 = tracers[(args.steps - 1) % in_flight].stats()
+        stats = member0
+        if in_flight > 1:
+            kernel_ms_sum = float("nan")
 
     if rank == 0:
-        samples_total = args.width * args.height * args.spp
         ms_per_step = elapsed / args.steps * 1e3
         value = samples_total * args.steps / elapsed / 1e6
-
-        flops = algorithmic_flops(stats["primary_samples"], stats["segments"], pod.n_spheres, pod.n_planes)
-        # one frame at a time: the launch duration from the HIP events.  Two frames in flight share the GPU, so a
-        # launch's own begin-to-end time says nothing about its rate: use the wall time per frame instead.
-        duration_ms = kernel_ms if in_flight == 1 else ms_per_step
+        kernel_ms = kernel_ms_sum / args.steps
+        # roofline of the dominant kernel: rank/member 0's launch (its share of the frame), algorithmic flops over its duration
+        flops = algorithmic_flops(member0["primary_samples"], member0["segments"], pod.n_spheres, pod.n_planes)
+        duration_ms = kernel_ms if kernel_ms == kernel_ms else ms_per_step  # NaN (two frames in flight): wall per frame
         achieved_tflops = flops / (duration_ms * 1e-3) / 1e12
-        local_rows = rt_amd.local_rows(args.height, 0, world)
+        local_rows = rt_amd.local_rows(args.height, 0, n_gpus)
         scene_bytes = 20 * pod.n_spheres + 20 * pod.n_planes + 28 * pod.n_materials
         hbm_bytes = 4 * args.width * local_rows + scene_bytes
         traffic = None
@@ -176,22 +235,22 @@ def main() -> None:
         if pmc.exists():
             try:
                 rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{world}"
+                key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}"
                 traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
             except (ValueError, OSError):
                 traffic = None
         roofline = {
             "bound": "valu_fp32",
-            "kernel": f"render_{stats['kernel']}",
+            "kernel": f"render_{member0['kernel']}",
             "achieved": round(achieved_tflops, 3),
             "peak": FP32_VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(achieved_tflops / FP32_VALU_PEAK_TFLOPS, 4),
             "traffic": traffic,
-            "kernel_ms": round(kernel_ms, 4),
-            "duration_used_ms": round(duration_ms, 4),
+            "kernel_ms": round(duration_ms, 4),
+            "kernel_ms_source": "HIP events on the launch stream around every launch of the timed region (rt_hip_stats.render_ms), averaged" if kernel_ms == kernel_ms else "wall per frame (two frames in flight)",
             "algorithmic_flops_per_launch": flops,
-            "mean_segments_per_sample": round(stats["segments"] / max(stats["primary_samples"], 1), 4),
+            "mean_segments_per_sample": round(member0["segments"] / max(member0["primary_samples"], 1), 4),
             "hbm": {
                 "algorithmic_bytes_per_launch": hbm_bytes,
                 "achieved_GBps": round(hbm_bytes / (duration_ms * 1e-3) / 1e9, 3),
@@ -199,11 +258,18 @@ def main() -> None:
                 "frac": round(hbm_bytes / (duration_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 6),
             },
         }
+        synthetic = args.scene.startswith("synthetic")
+        if n_gpus == 1:
+            parallelism = "1 GPU"
+        elif single_process:
+            parallelism = f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, {transport}, device assemble, one D2H"
+        else:
+            parallelism = f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {transport} to rank 0, device assemble, D2H on rank 0"
         line = {
             "metric": f"Mrays/s (W*H*spp per second) and wall-clock, {args.width}x{args.height}x{args.spp}spp scenes/{args.scene}.toml",
             "value": round(value, 1),
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": n_gpus,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
@@ -211,38 +277,34 @@ def main() -> None:
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic (generated sphere field, SURVEY.md §8d)" if synthetic else f"the reference's scene file scenes/{args.scene}.toml (no dataset; nothing is learned or loaded beyond the scene)",
             "config": {
                 "workload": f"scenes/{args.scene}.toml {args.width}x{args.height} {args.spp} spp max_bounces {args.max_bounces} seed {args.seed}",
+                "step": "one blocking render(): host scene in (columns fingerprinted, resident in HBM since warm-up), finished frame in the caller's host buffer out, one frame at a time",
                 "spheres": pod.n_spheres,
                 "planes": pod.n_planes,
-                "kernel": stats["kernel"],
-                "parallelism": f"row stripes of 8 over {world} GPU(s)" + (" + 1 RCCL gather to rank 0 + device assemble" if world > 1 else ""),
-                "frames_in_flight": in_flight,
+                "kernel": member0["kernel"],
+                "arithmetic": "contract v2-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v2 (bit-exact against the oracle)",
+                "parallelism": parallelism,
+                "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight),
             },
             "roofline": roofline,
         }
-        if world == 1:
-            # the drop-in call as rt makes it: host scene in, host frame out (upload + kernel + PCIe read-back); never `value`
-            import numpy as np
-
-            back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
-            walls = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                tracer.render(pod, args.width, args.height, seed=args.seed, flags=flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back_buffer)
-                walls.append(time.perf_counter() - t0)
-            wall = sorted(walls[1:])[len(walls[1:]) // 2]  # the first call page-locks the buffer and uploads the scene
-            line["drop_in_render"] = {"wall_ms": round(wall * 1e3, 3), "value": round(samples_total / wall / 1e6, 1), "unit": "Mrays/s", "includes": "scene fingerprint check (upload skipped when unchanged) + kernel + D2H of the frame into the caller's page-locked back buffer"}
-        if world == 1 and args.cpu_baseline_seconds > 0:
+        if single_process:
+            line["drop_in_breakdown"] = {"kernel_ms": round(kernel_ms, 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(ms_per_step, 4)}
+        if kernel_only:
+            line["kernel_only"] = kernel_only
+        if n_gpus == 1 and single_process and args.cpu_baseline_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
 
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    for t in tracers:
-        t.close()
+        for t in tracers:
+            t.close()
+    else:
+        tracer.close()
 
 
 if __name__ == "__main__":

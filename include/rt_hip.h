@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 2u
+#define RT_HIP_ABI_VERSION 3u
 
 typedef enum rt_hip_status
 {
@@ -138,7 +138,7 @@ typedef struct rt_hip_stats
 	uint64_t plane_tests;	  /* segments x n_planes */
 	float render_ms;		  /* device time of the render kernel(s), HIP events on the launch stream */
 	float upload_ms;		  /* host wall time of the last scene upload */
-	float readback_ms;		  /* host wall time of the last device-to-host frame copy (rt_hip_render only) */
+	float readback_ms;		  /* rt_hip_render only: host wall time from "kernels done" to "frame in the caller's buffer" */
 	uint32_t kernel_variant;  /* which kernel ran: RT_HIP_KERNEL_* */
 } rt_hip_stats;
 
@@ -161,9 +161,13 @@ enum
 	/* force the LDS-resident kernel for scenes that would take the scalar-register one (testing) */
 	RT_HIP_FLAG_FORCE_RESIDENT = 1u << 1,
 	/* rt_hip_render only: the caller promises that `pixels_rgba8888` stays allocated, at this address and size, until
-	 * the next rt_hip_render call on this context or rt_hip_destroy — as rt's back buffer does (one image per window
-	 * size, reference src/window.cpp:61-64, src/back_buffer.cpp).  The module then page-locks the buffer once and the
-	 * per-frame read-back becomes a single DMA.  Without the flag the buffer is treated as ordinary pageable memory. */
+	 * the next rt_hip_render call on this context, rt_hip_forget_frame or rt_hip_destroy — as rt's back buffer does (one
+	 * image per window size, reference src/window.cpp:61-64, src/back_buffer.cpp).  The module then page-locks the
+	 * buffer once and maps it into the GPU's address space: a single-GPU context stores every finished pixel straight
+	 * into it while the rest of the frame is still being traced (no read-back step at all), a multi-GPU context copies
+	 * the assembled frame with one DMA.  Without the flag the buffer is treated as ordinary pageable memory.
+	 * A caller that frees the buffer and may get the same address back from its allocator before the next frame calls
+	 * rt_hip_forget_frame() in between (the page-lock would otherwise still hold the old pages). */
 	RT_HIP_FLAG_PERSISTENT_FRAME = 1u << 2,
 	/* shade with sm_ray_tracer's scatter table (reference src/renderers/sm_ray_tracer.cpp:221-236) instead of
 	 * mg_ray_tracer's: dielectric, air, vacuum, water and ice refract/reflect through dielectric_scatter (:181-219),
@@ -199,6 +203,37 @@ rt_hip_status rt_hip_device_count(int* count);
  * description::create (src/renderer.hpp:39), destroyed through the virtual destructor (src/renderer.hpp:13). */
 rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device);
 void rt_hip_destroy(rt_hip_ctx* ctx);
+
+/*
+ * One renderer over SEVERAL GPUs of this process — what lets the reference's single blocking
+ * render(scene, back_buffer) call (src/renderers/mg_ray_tracer.cpp:178-205; the caller waits in it, src/window.cpp:213-217)
+ * use a whole node.  The context owns one member per entry of `devices`; rt_hip_render() on it then
+ *   - keeps the scene replicated on every member (each re-uploads only when the host columns changed),
+ *   - launches member r's share of the frame — rt_hip_partition{r, n_devices, RT_HIP_DEFAULT_STRIPE_ROWS} — on that
+ *     member's own stream, all members concurrently,
+ *   - collects the compact stripe buffers on devices[0] with ONE gather over xGMI (RCCL: a communicator per member from
+ *     ncclCommInitAll, one ncclGather inside a group call),
+ *   - de-interleaves them there and copies the frame to the caller's host buffer once.
+ * The frame is bit-identical to the single-GPU one (random streams are keyed by the global pixel index).
+ *   devices    device ordinals, rank order; devices[0] is the root.  NULL = 0 .. n_devices-1.
+ *   multi_flags RT_HIP_MULTI_*.
+ * Every other entry point (rt_hip_scene_upload, rt_hip_render_device, the known-answer calls, ...) used on such a context
+ * acts on the root member alone.  n_devices == 1 is allowed and still goes through the communicator.
+ */
+enum
+{
+	RT_HIP_MULTI_NONE = 0u,
+	/* move the stripes with hipMemcpyPeerAsync instead of RCCL.  RCCL refuses a communicator that names a device twice;
+	 * with this flag `devices` may (a one-GPU box can then exercise the whole multi-member path: tests). */
+	RT_HIP_MULTI_PEER_COPY = 1u << 0
+};
+rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags);
+/* number of members of a context (1 for rt_hip_create) and the device of member `rank` */
+rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count);
+rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device);
+/* counters of member `rank`'s share of the most recent rt_hip_render (rt_hip_stats_fetch on a multi context returns the
+ * whole frame: counts summed, render_ms = the slowest member) */
+rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_stats);
 
 /* ---- partition helpers (pure host arithmetic; usable without a GPU) ------------------------------------------- */
 
@@ -265,6 +300,9 @@ rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 							uint32_t flags,
 							float* rgb_f32,
 							rt_hip_stats* stats);
+
+/* Drop the page-lock taken under RT_HIP_FLAG_PERSISTENT_FRAME (see there).  Waits for the context's stream first. */
+void rt_hip_forget_frame(rt_hip_ctx* ctx);
 
 /* ---- known-answer entry points (device implementations of the path's leaf functions, for parity tests) -------- */
 

@@ -16,7 +16,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 
-RT_HIP_ABI_VERSION = 2
+RT_HIP_ABI_VERSION = 3
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
@@ -24,6 +24,7 @@ RT_HIP_FLAG_PERSISTENT_FRAME = 1 << 2
 RT_HIP_FLAG_SM_MATERIALS = 1 << 3
 RT_HIP_FLAG_PREVIEW = 1 << 4
 RT_HIP_FLAG_FORCE_STREAMED = 1 << 5
+RT_HIP_MULTI_PEER_COPY = 1 << 0
 KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview", 5: "streamed"}
 
 STATUS_NAMES = {
@@ -109,6 +110,10 @@ RT_HIP_SYMBOLS = [
     ("rt_hip_device_count", C.c_int, [C.POINTER(C.c_int)]),
     ("rt_hip_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     ("rt_hip_destroy", None, [C.c_void_p]),
+    ("rt_hip_create_multi", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_uint32]),
+    ("rt_hip_member_count", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
+    ("rt_hip_member_device", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    ("rt_hip_member_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(RtHipStats)]),
     ("rt_hip_local_rows", C.c_int, [C.c_uint32, C.POINTER(RtHipPartition), c_u32_p]),
     ("rt_hip_padded_local_rows", C.c_int, [C.c_uint32, C.POINTER(RtHipPartition), c_u32_p]),
     ("rt_hip_scene_upload", C.c_int, [C.c_void_p, C.POINTER(RtHipScene)]),
@@ -124,6 +129,7 @@ RT_HIP_SYMBOLS = [
         C.c_int,
         [C.c_void_p, C.POINTER(RtHipScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(RtHipStats)],
     ),
+    ("rt_hip_forget_frame", None, [C.c_void_p]),
     ("rt_hip_kat_random", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("rt_hip_kat_closest_hit", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_hip_kat_sqrt_div", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -7,6 +7,9 @@
 #include "contract.hpp"
 #include "kernels.hpp"
 
+#include <rccl/rccl.h>
+
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -38,6 +41,15 @@ namespace
 	{
 		return RT_HIP_OK;
 	}
+
+#define RT_HIP_TRY_NCCL(expr)                                                                                          \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		const ncclResult_t rt_hip_try_res = (expr);                                                                    \
+		if (rt_hip_try_res != ncclSuccess)                                                                             \
+			return fail(RT_HIP_RUNTIME_ERROR, "%s failed: %s", #expr, ncclGetErrorString(rt_hip_try_res));             \
+	}                                                                                                                  \
+	while (false)
 
 #define RT_HIP_TRY(expr)                                                                                               \
 	do                                                                                                                 \
@@ -120,9 +132,24 @@ struct rt_hip_ctx
 	float inverse_view_projection[16]{};
 
 	device_buffer counters;
-	hipEvent_t render_begin = nullptr, render_end = nullptr;
+	device_counters* counters_host = nullptr; // page-locked; filled by an asynchronous copy right behind every launch
+	hipEvent_t render_begin = nullptr, render_end = nullptr, counters_copied = nullptr;
 	bool render_recorded = false;
 	hipStream_t last_stream = nullptr;
+	launch_cache cache; // what the launch code remembers per context (occupancy of the persistent kernels)
+
+	// the context's own stream: everything rt_hip_render() enqueues goes here (never the process-wide null stream)
+	hipStream_t stream = nullptr;
+
+	// ---- several GPUs behind one render() (rt_hip_create_multi) ----
+	// The context the caller holds is member 0 (the root); it owns members 1 .. n-1, one per further device.
+	bool multi = false;
+	bool peer_copy = false;			  // RT_HIP_MULTI_PEER_COPY
+	std::vector<rt_hip_ctx*> peers;	  // members 1 .. n-1
+	std::vector<ncclComm_t> comms;	  // one communicator per member, rank order (empty with peer_copy)
+	device_buffer stripes_rgba, stripes_rgb;   // this member's compact stripe buffers (the gather's send side)
+	device_buffer gathered_rgba, gathered_rgb; // root: n x padded stripes, rank order (the gather's receive side)
+	hipEvent_t stripes_ready = nullptr;		   // recorded on `stream` after this member's launch (peer copies wait for it)
 
 	// staging for the drop-in rt_hip_render()
 	device_buffer frame_rgba, frame_rgb;
@@ -131,6 +158,7 @@ struct rt_hip_ctx
 	// back buffer once per window size, src/window.cpp:61-64): the read-back is then one DMA instead of a staged copy
 	void* pinned_frame = nullptr;
 	size_t pinned_bytes = 0;
+	bool store_to_host = true; // render straight into a page-locked back buffer (see rt_hip_render)
 
 	// KAT scratch
 	device_buffer kat_in, kat_out;
@@ -201,6 +229,14 @@ extern "C" rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device)
 		e = hipEventCreate(&ctx->render_begin);
 	if (e == hipSuccess)
 		e = hipEventCreate(&ctx->render_end);
+	if (e == hipSuccess)
+		e = hipEventCreateWithFlags(&ctx->stripes_ready, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = hipEventCreateWithFlags(&ctx->counters_copied, hipEventDisableTiming);
+	if (e == hipSuccess)
+		e = hipHostMalloc(reinterpret_cast<void**>(&ctx->counters_host), sizeof(device_counters), hipHostMallocDefault);
+	if (e == hipSuccess)
+		e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
 	if (e != hipSuccess)
 	{
 		rt_hip_destroy(ctx);
@@ -210,10 +246,124 @@ extern "C" rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device)
 	return ok();
 }
 
+extern "C" rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags)
+{
+	if (!out_ctx)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_multi: out_ctx is NULL");
+	*out_ctx = nullptr;
+	if (n_devices < 1 || n_devices > 64)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_multi: %d devices (1 .. 64 supported)", n_devices);
+	if (multi_flags & ~static_cast<uint32_t>(RT_HIP_MULTI_PEER_COPY))
+		return fail(RT_HIP_UNSUPPORTED, "rt_hip_create_multi: unknown flag bits 0x%x", multi_flags);
+	const bool peer_copy = (multi_flags & RT_HIP_MULTI_PEER_COPY) != 0;
+	try
+	{
+		std::vector<int> ordinals(static_cast<size_t>(n_devices));
+		for (int r = 0; r < n_devices; r++)
+			ordinals[static_cast<size_t>(r)] = devices ? devices[r] : r;
+		if (!peer_copy) // RCCL would fail later and less clearly
+			for (int a = 0; a < n_devices; a++)
+				for (int b = a + 1; b < n_devices; b++)
+					if (ordinals[static_cast<size_t>(a)] == ordinals[static_cast<size_t>(b)])
+						return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_multi: device %d is named twice (an RCCL communicator takes each device once; RT_HIP_MULTI_PEER_COPY allows it)", ordinals[static_cast<size_t>(a)]);
+
+		rt_hip_ctx* root = nullptr;
+		if (const rt_hip_status st = rt_hip_create(&root, ordinals[0]))
+			return st;
+		root->multi = true;
+		root->peer_copy = peer_copy;
+		for (int r = 1; r < n_devices; r++)
+		{
+			rt_hip_ctx* member = nullptr;
+			if (const rt_hip_status st = rt_hip_create(&member, ordinals[static_cast<size_t>(r)]))
+			{
+				rt_hip_destroy(root);
+				return st;
+			}
+			root->peers.push_back(member);
+		}
+		if (peer_copy)
+		{
+			// the root pulls the stripes itself: it needs access to the other members' memory
+			(void)hipSetDevice(root->device);
+			for (const rt_hip_ctx* member : root->peers)
+				if (member->device != root->device)
+				{
+					int can = 0;
+					(void)hipDeviceCanAccessPeer(&can, root->device, member->device);
+					if (can)
+					{
+						const hipError_t e = hipDeviceEnablePeerAccess(member->device, 0);
+						if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+						{
+							rt_hip_destroy(root);
+							return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_multi: hipDeviceEnablePeerAccess(%d) failed: %s", member->device, hipGetErrorString(e));
+						}
+						(void)hipGetLastError();
+					}
+					// without peer access hipMemcpyPeerAsync stages through the host: slower, still correct
+				}
+		}
+		else
+		{
+			// one communicator per member of THIS process (rccl.h: ncclCommInitAll); rank r = member r = ordinals[r]
+			root->comms.assign(static_cast<size_t>(n_devices), nullptr);
+			const ncclResult_t res = ncclCommInitAll(root->comms.data(), n_devices, ordinals.data());
+			if (res != ncclSuccess)
+			{
+				root->comms.clear();
+				rt_hip_destroy(root);
+				return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_multi: ncclCommInitAll over %d device(s) failed: %s", n_devices, ncclGetErrorString(res));
+			}
+		}
+		*out_ctx = root;
+		return ok();
+	}
+	catch (const std::exception& e)
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_multi: %s", e.what());
+	}
+}
+
+extern "C" rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count)
+{
+	if (!ctx || !out_count)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_member_count: NULL argument");
+	*out_count = 1 + static_cast<int>(ctx->peers.size());
+	return ok();
+}
+
+namespace
+{
+	rt_hip_ctx* member_of(rt_hip_ctx* ctx, int rank)
+	{
+		if (!ctx || rank < 0 || rank > static_cast<int>(ctx->peers.size()))
+			return nullptr;
+		return rank == 0 ? ctx : ctx->peers[static_cast<size_t>(rank - 1)];
+	}
+}
+
+extern "C" rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device)
+{
+	const rt_hip_ctx* member = member_of(const_cast<rt_hip_ctx*>(ctx), rank);
+	if (!member || !out_device)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_member_device: invalid argument");
+	*out_device = member->device;
+	return ok();
+}
+
 extern "C" void rt_hip_destroy(rt_hip_ctx* ctx)
 {
 	if (!ctx)
 		return;
+	// communicators first (they hold resources on every member's device), then the members, then the root
+	for (const ncclComm_t comm : ctx->comms)
+		if (comm)
+			(void)ncclCommDestroy(comm);
+	ctx->comms.clear();
+	for (rt_hip_ctx* member : ctx->peers)
+		rt_hip_destroy(member);
+	ctx->peers.clear();
 	(void)hipSetDevice(ctx->device);
 	(void)hipDeviceSynchronize();
 	unpin_frame(ctx);
@@ -221,12 +371,24 @@ extern "C" void rt_hip_destroy(rt_hip_ctx* ctx)
 	ctx->counters.release();
 	ctx->frame_rgba.release();
 	ctx->frame_rgb.release();
+	ctx->stripes_rgba.release();
+	ctx->stripes_rgb.release();
+	ctx->gathered_rgba.release();
+	ctx->gathered_rgb.release();
 	ctx->kat_in.release();
 	ctx->kat_out.release();
 	if (ctx->render_begin)
 		(void)hipEventDestroy(ctx->render_begin);
 	if (ctx->render_end)
 		(void)hipEventDestroy(ctx->render_end);
+	if (ctx->stripes_ready)
+		(void)hipEventDestroy(ctx->stripes_ready);
+	if (ctx->counters_copied)
+		(void)hipEventDestroy(ctx->counters_copied);
+	if (ctx->counters_host)
+		(void)hipHostFree(ctx->counters_host);
+	if (ctx->stream)
+		(void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
@@ -577,9 +739,12 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	if (flags & RT_HIP_FLAG_PREVIEW)
 		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
 	else
-		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), ctx->compute_units, s);
+		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), ctx->compute_units, ctx->cache, s);
 	RT_HIP_TRY(hipGetLastError());
 	RT_HIP_TRY(hipEventRecord(ctx->render_end, s));
+	// the counters follow the kernel to the host on the same stream: reading them later costs no transfer of its own
+	RT_HIP_TRY(hipMemcpyAsync(ctx->counters_host, ctx->counters.ptr, sizeof(device_counters), hipMemcpyDeviceToHost, s));
+	RT_HIP_TRY(hipEventRecord(ctx->counters_copied, s));
 	ctx->render_recorded = true;
 	ctx->last_stream = s;
 	ctx->stats.kernel_variant = variant;
@@ -610,28 +775,200 @@ extern "C" rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
 	return ok();
 }
 
+namespace
+{
+	// synchronise with the member's last launch and read its counters into member->stats
+	rt_hip_status fetch_member_stats(rt_hip_ctx* ctx)
+	{
+		RT_HIP_TRY(hipSetDevice(ctx->device));
+		if (ctx->render_recorded)
+		{
+			RT_HIP_TRY(hipEventSynchronize(ctx->counters_copied));
+			float ms = 0.0f;
+			RT_HIP_TRY(hipEventElapsedTime(&ms, ctx->render_begin, ctx->render_end));
+			ctx->stats.render_ms = ms;
+			uint64_t segments = 0;
+			for (const unsigned long long part : ctx->counters_host->segments)
+				segments += part;
+			ctx->stats.segments = segments;
+			ctx->stats.sphere_tests = segments * ctx->scene.n_spheres;
+			ctx->stats.plane_tests = segments * ctx->scene.n_planes;
+		}
+		return ok();
+	}
+}
+
 extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats)
 {
 	if (!ctx || !out_stats)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_stats_fetch: NULL argument");
-	RT_HIP_TRY(hipSetDevice(ctx->device));
-	if (ctx->render_recorded)
-	{
-		RT_HIP_TRY(hipEventSynchronize(ctx->render_end));
-		float ms = 0.0f;
-		RT_HIP_TRY(hipEventElapsedTime(&ms, ctx->render_begin, ctx->render_end));
-		ctx->stats.render_ms = ms;
-		device_counters host{};
-		RT_HIP_TRY(hipMemcpy(&host, ctx->counters.ptr, sizeof(host), hipMemcpyDeviceToHost));
-		uint64_t segments = 0;
-		for (const unsigned long long part : host.segments)
-			segments += part;
-		ctx->stats.segments = segments;
-		ctx->stats.sphere_tests = segments * ctx->scene.n_spheres;
-		ctx->stats.plane_tests = segments * ctx->scene.n_planes;
-	}
+	if (const rt_hip_status st = fetch_member_stats(ctx))
+		return st;
 	*out_stats = ctx->stats;
+	// several GPUs: the frame's counts are the sum over the members' shares, its kernel time the slowest member's
+	for (rt_hip_ctx* member : ctx->peers)
+	{
+		if (const rt_hip_status st = fetch_member_stats(member))
+			return st;
+		out_stats->primary_samples += member->stats.primary_samples;
+		out_stats->segments += member->stats.segments;
+		out_stats->sphere_tests += member->stats.sphere_tests;
+		out_stats->plane_tests += member->stats.plane_tests;
+		out_stats->render_ms = std::max(out_stats->render_ms, member->stats.render_ms);
+		out_stats->upload_ms = std::max(out_stats->upload_ms, member->stats.upload_ms);
+	}
+	if (!ctx->peers.empty())
+		RT_HIP_TRY(hipSetDevice(ctx->device));
 	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_stats)
+{
+	rt_hip_ctx* member = member_of(ctx, rank);
+	if (!member || !out_stats)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_member_stats: invalid argument");
+	if (const rt_hip_status st = fetch_member_stats(member))
+		return st;
+	*out_stats = member->stats;
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	return ok();
+}
+
+namespace
+{
+	constexpr uint32_t render_flag_mask = RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED;
+
+	// image_view memory is ordinary pageable host memory (reference src/image.cpp:9-13).  With
+	// RT_HIP_FLAG_PERSISTENT_FRAME it is page-locked on first sight and stays so while the same buffer keeps arriving;
+	// any other buffer (or no flag) first drops the old registration — before anything else touches host memory.
+	void track_frame_buffer(rt_hip_ctx* ctx, uint32_t* pixels, size_t bytes, bool pin)
+	{
+		if (ctx->pinned_frame && (!pin || ctx->pinned_frame != pixels || ctx->pinned_bytes != bytes))
+			unpin_frame(ctx);
+		if (pin && !ctx->pinned_frame)
+		{
+			if (hipHostRegister(pixels, bytes, hipHostRegisterMapped) == hipSuccess)
+			{
+				ctx->pinned_frame = pixels;
+				ctx->pinned_bytes = bytes;
+			}
+			else
+				(void)hipGetLastError(); // not fatal: the read-back then stages through the driver's bounce buffers
+		}
+	}
+
+	// rt_hip_render on a context made by rt_hip_create_multi
+	rt_hip_status render_multi(rt_hip_ctx* root,
+							   const rt_hip_scene* scene,
+							   uint32_t* pixels_rgba8888,
+							   uint32_t width,
+							   uint32_t height,
+							   uint64_t seed,
+							   uint32_t flags,
+							   float* rgb_f32,
+							   rt_hip_stats* stats)
+	{
+		const int n = 1 + static_cast<int>(root->peers.size());
+		const uint32_t world = static_cast<uint32_t>(n);
+		const rt_hip_partition whole = { 0, world, RT_HIP_DEFAULT_STRIPE_ROWS };
+		uint32_t padded_rows = 0;
+		if (const rt_hip_status st = rt_hip_padded_local_rows(height, &whole, &padded_rows))
+			return st;
+		const size_t pixels = static_cast<size_t>(width) * height;
+		const size_t stripe_pixels = static_cast<size_t>(padded_rows) * width; // what every member sends
+		if (stripe_pixels * 3u > 0x7FFFFFFFull)
+			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: a %ux%u frame over %d devices exceeds the gather's element count", width, height, n);
+
+		// 1. every member: scene resident (re-uploaded only when the host columns changed), its share of the frame
+		//    launched on its own stream.  Nothing here waits for a GPU, so the members run concurrently.
+		for (int r = 0; r < n; r++)
+		{
+			rt_hip_ctx* member = member_of(root, r);
+			if (const rt_hip_status st = rt_hip_scene_upload(member, scene))
+				return st;
+			RT_HIP_TRY(member->stripes_rgba.reserve(stripe_pixels * sizeof(uint32_t)));
+			if (rgb_f32)
+				RT_HIP_TRY(member->stripes_rgb.reserve(stripe_pixels * 3 * sizeof(float)));
+			const rt_hip_partition part = { static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
+			if (const rt_hip_status st = rt_hip_render_device(member, width, height, seed, flags & render_flag_mask, &part, member->stripes_rgba.as<uint32_t>(), rgb_f32 ? member->stripes_rgb.as<float>() : nullptr, member->stream))
+				return st;
+			RT_HIP_TRY(hipEventRecord(member->stripes_ready, member->stream));
+		}
+
+		// 2. ONE gather of the compact stripe buffers to the root, rank order
+		RT_HIP_TRY(hipSetDevice(root->device));
+		RT_HIP_TRY(root->gathered_rgba.reserve(stripe_pixels * sizeof(uint32_t) * world));
+		if (rgb_f32)
+			RT_HIP_TRY(root->gathered_rgb.reserve(stripe_pixels * 3 * sizeof(float) * world));
+		if (root->peer_copy)
+		{
+			for (int r = 0; r < n; r++)
+			{
+				rt_hip_ctx* member = member_of(root, r);
+				if (r)
+					RT_HIP_TRY(hipStreamWaitEvent(root->stream, member->stripes_ready, 0));
+				RT_HIP_TRY(hipMemcpyPeerAsync(root->gathered_rgba.as<uint32_t>() + stripe_pixels * static_cast<size_t>(r), root->device, member->stripes_rgba.ptr, member->device, stripe_pixels * sizeof(uint32_t), root->stream));
+				if (rgb_f32)
+					RT_HIP_TRY(hipMemcpyPeerAsync(root->gathered_rgb.as<float>() + stripe_pixels * 3 * static_cast<size_t>(r), root->device, member->stripes_rgb.ptr, member->device, stripe_pixels * 3 * sizeof(float), root->stream));
+			}
+		}
+		else
+		{
+			// rccl.h: ncclGather(sendbuff, recvbuff, sendcount, datatype, root, comm, stream); recvbuff is read on the
+			// root only.  One communicator per member, so the calls of all members go into one group.
+			RT_HIP_TRY_NCCL(ncclGroupStart());
+			ncclResult_t res = ncclSuccess;
+			for (int r = 0; r < n && res == ncclSuccess; r++)
+			{
+				rt_hip_ctx* member = member_of(root, r);
+				res = ncclGather(member->stripes_rgba.ptr, r == 0 ? root->gathered_rgba.ptr : nullptr, stripe_pixels, ncclUint32, 0, root->comms[static_cast<size_t>(r)], member->stream);
+				if (res == ncclSuccess && rgb_f32)
+					res = ncclGather(member->stripes_rgb.ptr, r == 0 ? root->gathered_rgb.ptr : nullptr, stripe_pixels * 3, ncclFloat, 0, root->comms[static_cast<size_t>(r)], member->stream);
+			}
+			const ncclResult_t end = ncclGroupEnd();
+			RT_HIP_TRY_NCCL(res);
+			RT_HIP_TRY_NCCL(end);
+		}
+
+		// 3. root: de-interleave into the frame, one copy to the host
+		RT_HIP_TRY(hipSetDevice(root->device));
+		RT_HIP_TRY(root->frame_rgba.reserve(pixels * sizeof(uint32_t)));
+		launch_assemble(width, height, world, RT_HIP_DEFAULT_STRIPE_ROWS, padded_rows, root->gathered_rgba.as<uint32_t>(), root->frame_rgba.as<uint32_t>(), root->stream);
+		RT_HIP_TRY(hipGetLastError());
+		RT_HIP_TRY(hipMemcpyAsync(pixels_rgba8888, root->frame_rgba.ptr, pixels * sizeof(uint32_t), hipMemcpyDeviceToHost, root->stream));
+		if (rgb_f32)
+		{
+			RT_HIP_TRY(root->frame_rgb.reserve(pixels * 3 * sizeof(float)));
+			launch_assemble(width * 3u, height, world, RT_HIP_DEFAULT_STRIPE_ROWS, padded_rows, root->gathered_rgb.as<uint32_t>(), root->frame_rgb.as<uint32_t>(), root->stream);
+			RT_HIP_TRY(hipGetLastError());
+			RT_HIP_TRY(hipMemcpyAsync(rgb_f32, root->frame_rgb.ptr, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, root->stream));
+		}
+		RT_HIP_TRY(hipEventSynchronize(root->render_end)); // (the root's own kernel: where the read-back clock starts)
+		const auto t0 = std::chrono::steady_clock::now();
+		RT_HIP_TRY(hipStreamSynchronize(root->stream));
+		root->stats.readback_ms = static_cast<float>(seconds_since(t0) * 1e3);
+		// the other members' streams end with their send, which the root's receive has already waited for; settle them
+		// anyway, so that a caller who changes the scene next finds every device idle
+		for (rt_hip_ctx* member : root->peers)
+		{
+			RT_HIP_TRY(hipSetDevice(member->device));
+			RT_HIP_TRY(hipStreamSynchronize(member->stream));
+		}
+		RT_HIP_TRY(hipSetDevice(root->device));
+		if (stats)
+			return rt_hip_stats_fetch(root, stats);
+		return ok();
+	}
+}
+
+extern "C" void rt_hip_forget_frame(rt_hip_ctx* ctx)
+{
+	if (!ctx)
+		return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream)
+		(void)hipStreamSynchronize(ctx->stream);
+	unpin_frame(ctx);
 }
 
 extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
@@ -648,42 +985,60 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: NULL argument");
 	if (!width || !height)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: empty frame %ux%u", width, height);
+	if (flags & ~(render_flag_mask | static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME)))
+		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render: unknown flag bits 0x%x", flags);
 	const size_t pixels = static_cast<size_t>(width) * height;
-	// image_view memory is ordinary pageable host memory (reference src/image.cpp:9-13).  With
-	// RT_HIP_FLAG_PERSISTENT_FRAME it is page-locked on first sight and stays so while the same buffer keeps arriving;
-	// any other buffer (or no flag) first drops the old registration — before anything else touches host memory.
-	RT_HIP_TRY(hipSetDevice(ctx->device));
-	const bool pin = (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0;
-	if (ctx->pinned_frame && (!pin || ctx->pinned_frame != pixels_rgba8888 || ctx->pinned_bytes != pixels * sizeof(uint32_t)))
-		unpin_frame(ctx);
-	if (pin && !ctx->pinned_frame)
-	{
-		if (hipHostRegister(pixels_rgba8888, pixels * sizeof(uint32_t), hipHostRegisterDefault) == hipSuccess)
-		{
-			ctx->pinned_frame = pixels_rgba8888;
-			ctx->pinned_bytes = pixels * sizeof(uint32_t);
-		}
-		else
-			(void)hipGetLastError(); // not fatal: the read-back then stages through the driver's bounce buffers
-	}
-	if (const rt_hip_status st = rt_hip_scene_upload(ctx, scene))
-		return st;
-	RT_HIP_TRY(ctx->frame_rgba.reserve(pixels * sizeof(uint32_t)));
-	if (rgb_f32)
-		RT_HIP_TRY(ctx->frame_rgb.reserve(pixels * 3 * sizeof(float)));
-	if (const rt_hip_status st =
-			rt_hip_render_device(ctx, width, height, seed, flags & ~static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME), nullptr, ctx->frame_rgba.as<uint32_t>(), rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, nullptr))
-		return st;
 	const size_t frame_bytes = pixels * sizeof(uint32_t);
-	RT_HIP_TRY(hipStreamSynchronize(nullptr));
-	const auto t0 = std::chrono::steady_clock::now();
-	RT_HIP_TRY(hipMemcpy(pixels_rgba8888, ctx->frame_rgba.ptr, frame_bytes, hipMemcpyDeviceToHost));
-	if (rgb_f32)
-		RT_HIP_TRY(hipMemcpy(rgb_f32, ctx->frame_rgb.ptr, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost));
-	ctx->stats.readback_ms = static_cast<float>(seconds_since(t0) * 1e3);
-	if (stats)
-		return rt_hip_stats_fetch(ctx, stats);
-	return ok();
+	try
+	{
+		RT_HIP_TRY(hipSetDevice(ctx->device));
+		track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0);
+		if (ctx->multi)
+			return render_multi(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats);
+
+		if (const rt_hip_status st = rt_hip_scene_upload(ctx, scene))
+			return st;
+		// A page-locked back buffer is mapped into the device's address space: the kernel stores every finished pixel
+		// straight into it (4 bytes per pixel over PCIe while the rest of the frame is still being traced), and
+		// there is no read-back step at all.  Otherwise the frame is rendered into HBM and copied.
+		uint32_t* d_frame = nullptr;
+		bool mapped = false;
+		if (ctx->pinned_frame && ctx->store_to_host)
+		{
+			void* device_view = nullptr;
+			if (hipHostGetDevicePointer(&device_view, pixels_rgba8888, 0) == hipSuccess && device_view)
+			{
+				d_frame = static_cast<uint32_t*>(device_view);
+				mapped = true;
+			}
+			else
+				(void)hipGetLastError();
+		}
+		if (!mapped)
+		{
+			RT_HIP_TRY(ctx->frame_rgba.reserve(frame_bytes));
+			d_frame = ctx->frame_rgba.as<uint32_t>();
+		}
+		if (rgb_f32)
+			RT_HIP_TRY(ctx->frame_rgb.reserve(pixels * 3 * sizeof(float)));
+		if (const rt_hip_status st = rt_hip_render_device(ctx, width, height, seed, flags & render_flag_mask, nullptr, d_frame, rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, ctx->stream))
+			return st;
+		if (!mapped)
+			RT_HIP_TRY(hipMemcpyAsync(pixels_rgba8888, d_frame, frame_bytes, hipMemcpyDeviceToHost, ctx->stream));
+		if (rgb_f32)
+			RT_HIP_TRY(hipMemcpyAsync(rgb_f32, ctx->frame_rgb.ptr, pixels * 3 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+		RT_HIP_TRY(hipEventSynchronize(ctx->render_end));
+		const auto t0 = std::chrono::steady_clock::now();
+		RT_HIP_TRY(hipStreamSynchronize(ctx->stream));
+		ctx->stats.readback_ms = static_cast<float>(seconds_since(t0) * 1e3);
+		if (stats)
+			return rt_hip_stats_fetch(ctx, stats);
+		return ok();
+	}
+	catch (const std::exception& e) // nothing may propagate through the C boundary
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: %s", e.what());
+	}
 }
 
 // ---- known-answer entry points --------------------------------------------------------------------------------------

@@ -36,7 +36,6 @@
 #include "../../include/rt_hip.h"
 
 #include <algorithm>
-#include <cstdlib>
 
 // waves per SIMD the kernel variants are compiled for (register budget = 512 / waves): measured, see render_queue
 #ifndef RT_HIP_WAVES_FEW
@@ -878,6 +877,7 @@ namespace rt_hip
 		}
 
 		// ---- multi-GPU assemble: rank-major compact stripes -> frame ------------------------------------------------
+		// `width` counts 32-bit words per row: pixels for the RGBA8888 frame, 3 x pixels for the float mean
 		__global__ __launch_bounds__(block_threads) void assemble_stripes(uint32_t width,
 																		  uint32_t height,
 																		  uint32_t world,
@@ -1025,21 +1025,24 @@ namespace rt_hip
 							 float* d_rgb_f32,
 							 device_counters* d_counters,
 							 uint32_t compute_units,
+							 launch_cache& cache,
 							 hipStream_t stream)
 		{
 			if (NS < 0)
 			{
-				// persistent launch: exactly what the device keeps resident (surplus workgroups would only find the queue dry)
-				static size_t asked_for = ~static_cast<size_t>(0);
-				static int per_cu = 0;
-				if (asked_for != lds_bytes)
+				// persistent launch: exactly what the device keeps resident (surplus workgroups would only find the queue dry).
+				// The answer is remembered per context (= per device and host thread of use), per kernel and LDS size.
+				launch_cache::entry& known = cache.persistent[(NS == -1 ? 0 : 2) + (SM ? 1 : 0)];
+				if (known.lds_bytes != lds_bytes || known.per_cu < 1)
 				{
+					int per_cu = 0;
 					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes) != hipSuccess || per_cu < 1)
 						per_cu = 4;
 					(void)hipGetLastError();
-					asked_for = lds_bytes;
+					known.lds_bytes = lds_bytes;
+					known.per_cu = per_cu;
 				}
-				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(per_cu)));
+				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(known.per_cu)));
 			}
 			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters);
 		}
@@ -1056,12 +1059,13 @@ namespace rt_hip
 						  float* d_rgb_f32,
 						  device_counters* d_counters,
 						  uint32_t compute_units,
+						  launch_cache& cache,
 						  hipStream_t stream)
 		{
 			if (sm)
-				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
+				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 			else
-				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
+				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 		}
 	}
 
@@ -1106,8 +1110,6 @@ namespace rt_hip
 			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
 			if (pixels_log2 > 2 && (pixels >> pixels_log2) < 49152u)
 				pixels_log2--;
-			if (const char* e = std::getenv("RT_HIP_PIXELS_LOG2")) // experiments only (tools/gpu_partition_times.py)
-				pixels_log2 = static_cast<uint32_t>(std::atoi(e));
 		}
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
@@ -1125,6 +1127,7 @@ namespace rt_hip
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
 						   uint32_t compute_units,
+						   launch_cache& cache,
 						   hipStream_t stream)
 	{
 		if (!frame.width || !frame.local_rows)
@@ -1145,29 +1148,29 @@ namespace rt_hip
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
 			switch (scene.n_spheres)
 			{
-				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
-				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream); break;
+				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
 			}
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
 			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
-			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
+			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_STREAMED)
 		{
-			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
+			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 			return variant;
 		}
-		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, stream);
+		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 		return variant;
 	}
 

@@ -108,6 +108,17 @@ namespace rt_hip
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
+	// what a context remembers between launches: workgroups per CU that stay resident, for the persistent (big-scene) kernels
+	struct launch_cache
+	{
+		struct entry
+		{
+			size_t lds_bytes = 0;
+			int per_cu = 0;
+		};
+		entry persistent[4]; // { tiled, streamed } x { mg, sm scatter table }
+	};
+
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
 	uint32_t choose_kernel(const device_scene& scene, uint32_t flags);
 
@@ -120,11 +131,13 @@ namespace rt_hip
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
 						   uint32_t compute_units, // of the device: the big-scene kernels are launched persistent
+						   launch_cache& cache,
 						   hipStream_t stream);
 
 	// RT_HIP_FLAG_PREVIEW: one ray per pixel, reference src/renderers/rasterizer.cpp:24-85
 	void launch_preview(const frame_params& frame, const device_scene& scene, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream);
 
+	// `width` in 32-bit words per row (pixels, or 3 x pixels for the float mean)
 	void launch_assemble(uint32_t width,
 						 uint32_t height,
 						 uint32_t world,

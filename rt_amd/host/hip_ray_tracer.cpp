@@ -17,12 +17,49 @@
 
 #include <atomic>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 using namespace rt;
 
 namespace
 {
+	// RT_HIP_DEVICES picks the GPUs: unset = GPU 0 (or RT_HIP_DEVICE=<n>); "all" = every visible GPU; "0,1,2,3" = those, the
+	// first being the root that assembles the frame.  More than one GPU = one rt_hip_create_multi context: the frame is
+	// split into row stripes, gathered over RCCL and delivered by the same single blocking call.
+	rt_hip_status create_context(rt_hip_ctx** ctx)
+	{
+		const char* list = std::getenv("RT_HIP_DEVICES");
+		if (!list || !*list)
+		{
+			const char* device = std::getenv("RT_HIP_DEVICE");
+			return rt_hip_create(ctx, device ? std::atoi(device) : 0);
+		}
+		int devices[64];
+		int n = 0;
+		if (std::strcmp(list, "all") == 0)
+		{
+			if (rt_hip_device_count(&n) != RT_HIP_OK)
+				return RT_HIP_NO_DEVICE;
+			n = n > 64 ? 64 : n;
+			for (int i = 0; i < n; i++)
+				devices[i] = i;
+		}
+		else
+		{
+			for (const char* p = list; *p && n < 64;)
+			{
+				char* end = nullptr;
+				const long v = std::strtol(p, &end, 10);
+				if (end == p)
+					break;
+				devices[n++] = static_cast<int>(v);
+				p = (*end == ',') ? end + 1 : end;
+			}
+		}
+		return rt_hip_create_multi(ctx, devices, n, RT_HIP_MULTI_NONE); // n == 0 fails there with a message
+	}
+
 	// ModeFlags: 0 = mg_ray_tracer's scatter table; RT_HIP_FLAG_SM_MATERIALS = sm_ray_tracer's (dielectrics refract);
 	// RT_HIP_FLAG_PREVIEW = the one-ray-per-pixel preview of src/renderers/rasterizer.cpp
 	template <uint32_t ModeFlags>
@@ -38,15 +75,11 @@ namespace
 		{
 			if (!pixels || failed_to_create)
 				return;
-			if (!ctx)
+			if (!ctx && create_context(&ctx) != RT_HIP_OK)
 			{
-				const char* device = std::getenv("RT_HIP_DEVICE");
-				if (rt_hip_create(&ctx, device ? std::atoi(device) : 0) != RT_HIP_OK)
-				{
-					std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
-					failed_to_create = true;
-					return;
-				}
+				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+				failed_to_create = true;
+				return;
 			}
 
 			rt_hip_scene s{};

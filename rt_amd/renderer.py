@@ -41,11 +41,22 @@ def device_count() -> int:
 
 
 class HipRayTracer:
-    def __init__(self, device: int = 0):
+    """`device`: one GPU (rt_hip_create).  `devices`: a list of GPUs behind ONE render() call (rt_hip_create_multi):
+    scene replicated, row stripes dealt round-robin, one RCCL gather to devices[0], one copy to the host.
+    `peer_copy`: move the stripes with hipMemcpyPeerAsync instead of RCCL (allows a device to appear twice: tests)."""
+
+    def __init__(self, device: int = 0, devices: list[int] | None = None, peer_copy: bool = False):
         self._lib = capi.hip_lib()
         self._ctx = C.c_void_p()
-        check(self._lib.rt_hip_create(C.byref(self._ctx), device))
-        self.device = device
+        if devices is None:
+            check(self._lib.rt_hip_create(C.byref(self._ctx), device))
+            self.device = device
+            self.devices = [device]
+        else:
+            ordinals = (C.c_int * len(devices))(*devices)
+            check(self._lib.rt_hip_create_multi(C.byref(self._ctx), ordinals, len(devices), capi.RT_HIP_MULTI_PEER_COPY if peer_copy else 0))
+            self.device = devices[0]
+            self.devices = list(devices)
 
     def close(self) -> None:
         ctx, self._ctx = getattr(self, "_ctx", None), None
@@ -84,6 +95,10 @@ class HipRayTracer:
         )
         return rgba, rgb, stats.as_dict()
 
+    def forget_frame(self) -> None:
+        """Drop the page-lock on the back buffer last rendered into with RT_HIP_FLAG_PERSISTENT_FRAME."""
+        self._lib.rt_hip_forget_frame(self._ctx)
+
     def preview(self, scene: RtHipScene, width: int, height: int, want_rgb: bool = False, out: np.ndarray | None = None):
         """The one-ray-per-pixel preview (reference src/renderers/rasterizer.cpp) through the same drop-in call."""
         return self.render(scene, width, height, seed=0, flags=capi.RT_HIP_FLAG_PREVIEW, want_rgb=want_rgb, out=out)
@@ -112,6 +127,22 @@ class HipRayTracer:
     def stats(self) -> dict:
         stats = RtHipStats()
         check(self._lib.rt_hip_stats_fetch(self._ctx, C.byref(stats)))
+        return stats.as_dict()
+
+    def member_count(self) -> int:
+        n = C.c_int()
+        check(self._lib.rt_hip_member_count(self._ctx, C.byref(n)))
+        return n.value
+
+    def member_device(self, rank: int) -> int:
+        d = C.c_int()
+        check(self._lib.rt_hip_member_device(self._ctx, rank, C.byref(d)))
+        return d.value
+
+    def member_stats(self, rank: int) -> dict:
+        """Counters of member `rank`'s share of the last render() on a multi-GPU tracer."""
+        stats = RtHipStats()
+        check(self._lib.rt_hip_member_stats(self._ctx, rank, C.byref(stats)))
         return stats.as_dict()
 
     # ---- known-answer entry points ------------------------------------------------------------------------

@@ -43,7 +43,22 @@ def test_single_gpu_line_has_the_contract_keys_roofline_and_cpu_baseline():
     assert roof["frac"] == pytest.approx(roof["achieved"] / roof["peak"], abs=1e-3) and 0 < roof["frac"] < 1
     cpu = line["cpu_baseline"]
     assert {"value", "unit", "cores", "kind", "sample"} <= set(cpu) and cpu["kind"] == "port" and cpu["cores"] >= 1
-    assert line["drop_in_render"]["wall_ms"] > 0
+    # `value` is the drop-in call (host scene in, host frame out, one frame at a time); the kernel-only rate rides along
+    assert line["config"]["frames_in_flight"] == 1 and "blocking render()" in line["config"]["step"]
+    assert line["drop_in_breakdown"]["wall_ms"] == pytest.approx(line["ms_per_step"])
+    assert line["drop_in_breakdown"]["kernel_ms"] <= line["ms_per_step"]
+    assert line["kernel_only"]["value"] >= 0.95 * line["value"]
+    assert "scenes/basic.toml" in line["data"]
+    assert "EPYC" in cpu["sample"] or "CPU" in cpu["sample"] or "Xeon" in cpu["sample"]
+
+
+@pytest.mark.gpu
+def test_one_process_drives_several_members_through_the_c_abi():
+    """`bench.py --gpus N` outside torchrun = ONE process, rt_hip_create_multi + rt_hip_render: the form the reference's
+    blocking render() can use.  On this one-GPU box the N members share device 0 (--same-device: peer copies)."""
+    line = run_bench(["--gpus", "4", "--same-device", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0"])
+    assert line["n_gpus"] == 4 and "ONE process" in line["config"]["parallelism"] and "cpu_baseline" not in line
+    assert line["value"] == pytest.approx(1920 * 1080 * 16 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
 
 
 @pytest.mark.gpu
@@ -58,4 +73,4 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_step():
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
     line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
-    assert "RCCL gather" in line["config"]["parallelism"]
+    assert "one process per GPU" in line["config"]["parallelism"] and line["config"]["frames_in_flight"] == 1

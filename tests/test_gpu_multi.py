@@ -1,0 +1,136 @@
+"""Several GPUs behind ONE blocking render() call: rt_hip_create_multi + rt_hip_render (include/rt_hip.h).
+
+This is the multi-GPU form the reference can actually use — its renderer interface is a single blocking
+``render(scene, back_buffer)`` (reference src/renderer.hpp:9-14, src/renderers/mg_ray_tracer.cpp:203-204): the
+partition, the RCCL gather, the de-interleave and the one device-to-host copy all happen inside librt_hip.so.
+
+A GPU box of this pool has ONE device, so:
+  * n = 1 goes through the real thing — ncclCommInitAll, ncclGather inside a group call, assemble, copy;
+  * n = 2, 3, 4, 8 members are all placed on device 0 with RT_HIP_MULTI_PEER_COPY (RCCL refuses a communicator that
+    names a device twice): everything but the transport is the code an 8-GPU node runs — replicated uploads, one
+    launch per member on its own stream, the gather layout, assemble_stripes, the read-back.
+Every frame must equal the oracle's bit for bit (RGBA8888 and the float32 mean).
+"""
+import threading
+
+import numpy as np
+import pytest
+
+import rt_amd
+from oracle import binding as oracle
+from rt_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(name, spp, bounces=10):
+    return rt_amd.Scene.named(name).set_sampling(spp, bounces)
+
+
+def test_one_member_renders_through_the_rccl_communicator():
+    width, height, seed = 200, 117, 3  # ragged: 117 rows = 14 stripes of 8 + one of 5
+    pod = _scene("basic", 5).describe(width, height)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    with rt_amd.HipRayTracer(devices=[0]) as tracer:  # RCCL transport: ncclCommInitAll over one device
+        assert tracer.member_count() == 1 and tracer.member_device(0) == 0
+        for _ in range(2):  # the second frame reuses communicator, buffers and the resident scene
+            rgba, rgb, stats = tracer.render(pod, width, height, seed=seed, want_rgb=True)
+            assert np.array_equal(rgba, want_rgba)
+            assert np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32))
+            assert stats["segments"] == want_stats["segments"] and stats["primary_samples"] == width * height * 5
+
+
+@pytest.mark.parametrize("members", [2, 3, 4, 8])
+@pytest.mark.parametrize("name,width,height,spp", [("basic", 256, 144, 20), ("dielectric", 131, 77, 4), ("synthetic-1500", 64, 36, 2)])
+def test_members_on_one_device_assemble_the_oracle_frame(members, name, width, height, spp):
+    seed = 11
+    pod = _scene(name, spp).describe(width, height)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    with rt_amd.HipRayTracer(devices=[0] * members, peer_copy=True) as tracer:
+        assert tracer.member_count() == members
+        rgba, rgb, stats = tracer.render(pod, width, height, seed=seed, want_rgb=True)
+        assert np.array_equal(rgba, want_rgba), f"{(rgba != want_rgba).sum()} pixels differ"
+        assert np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32))
+        assert stats["segments"] == want_stats["segments"]
+        # every member traced its own share and nothing else
+        shares = [tracer.member_stats(r) for r in range(members)]
+        assert sum(s["segments"] for s in shares) == want_stats["segments"]
+        for r, share in enumerate(shares):
+            assert share["primary_samples"] == rt_amd.local_rows(height, r, members) * width * spp
+        # ... and with the caller's buffer kept across frames (rt's back buffer): page-locked once
+        back_buffer = np.zeros((height, width), dtype=np.uint32)
+        for frame_seed in (seed, seed + 1, seed):
+            tracer.render(pod, width, height, seed=frame_seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back_buffer)
+        assert np.array_equal(back_buffer, want_rgba)
+
+
+def test_multi_context_follows_scene_and_size_changes():
+    """rt re-renders after every edit and resize (reference src/main.cpp:233-311, src/window.cpp:198-203)."""
+    with rt_amd.HipRayTracer(devices=[0, 0, 0], peer_copy=True) as tracer:
+        for name, width, height, spp, seed in [("basic", 96, 54, 3, 1), ("dielectric", 160, 90, 2, 2), ("basic", 64, 8, 1, 3), ("basic", 96, 54, 3, 1)]:
+            pod = _scene(name, spp).describe(width, height)
+            want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+            got, _, _ = tracer.render(pod, width, height, seed=seed)
+            assert np.array_equal(got, want), (name, width, height)
+
+
+def test_more_members_than_stripes():
+    # 8 rows = one stripe: members 1..3 own nothing and must neither launch nor disturb the gather
+    width, height = 40, 8
+    pod = _scene("basic", 2).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=9, want_rgb=False)
+    with rt_amd.HipRayTracer(devices=[0] * 4, peer_copy=True) as tracer:
+        got, _, stats = tracer.render(pod, width, height, seed=9)
+        assert np.array_equal(got, want)
+        assert tracer.member_stats(1)["primary_samples"] == 0
+
+
+def test_multi_preview_and_sm_table_go_through_the_same_path():
+    width, height = 120, 67
+    pod = _scene("dielectric", 3).describe(width, height)
+    with rt_amd.HipRayTracer(devices=[0, 0], peer_copy=True) as tracer:
+        want, _, _ = oracle.render(pod, width, height, seed=4, want_rgb=False, sm_materials=True)
+        got, _, _ = tracer.render(pod, width, height, seed=4, flags=capi.RT_HIP_FLAG_SM_MATERIALS)
+        assert np.array_equal(got, want)
+        want, _, _ = oracle.render(pod, width, height, want_rgb=False, preview=True)
+        got, _, _ = tracer.preview(pod, width, height)
+        assert np.array_equal(got, want)
+
+
+def test_rccl_refuses_duplicates_with_a_clear_message_and_bad_arguments_fail():
+    with pytest.raises(rt_amd.RtHipError, match="named twice"):
+        rt_amd.HipRayTracer(devices=[0, 0])
+    with pytest.raises(rt_amd.RtHipError, match="out of range"):
+        rt_amd.HipRayTracer(devices=[0, 99], peer_copy=True)
+    with pytest.raises(rt_amd.RtHipError):
+        rt_amd.HipRayTracer(devices=[])
+
+
+def test_two_contexts_on_one_device_used_from_two_host_threads(tracer):
+    """VERDICT r1 hygiene: nothing in the launch path may be shared between contexts (the occupancy cache of the persistent
+    kernels used to live in function statics).  Two contexts, two host threads, big- and small-scene kernels at once."""
+    jobs = [("synthetic-1500", 96, 54, 2, capi.RT_HIP_FLAG_FORCE_TILED, 5), ("basic", 320, 180, 8, 0, 6)]
+    want = {}
+    for name, width, height, spp, flags, seed in jobs:
+        pod = _scene(name, spp).describe(width, height)
+        want[name] = oracle.render(pod, width, height, seed=seed, want_rgb=False)[0]
+    errors = []
+
+    def work(job):
+        name, width, height, spp, flags, seed = job
+        try:
+            pod = _scene(name, spp).describe(width, height)
+            with rt_amd.HipRayTracer(device=0) as mine:
+                for _ in range(6):
+                    got, _, _ = mine.render(pod, width, height, seed=seed, flags=flags)
+                    if not np.array_equal(got, want[name]):
+                        errors.append(f"{name}: frame differs")
+        except Exception as e:  # noqa: BLE001 - reported below, in the main thread
+            errors.append(f"{name}: {e!r}")
+
+    threads = [threading.Thread(target=work, args=(job,)) for job in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

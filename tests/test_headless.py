@@ -87,3 +87,33 @@ def test_hip_rasterizer_plugin_draws_the_oracle_preview_boxes_included(tmp_path)
     got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(67, 120, 3)
     want, _, _ = oracle.render(rt_amd.Scene.parse(PREVIEW_SCENE).describe(120, 67), 120, 67, want_rgb=False, preview=True)
     assert np.array_equal(got, unpack(want)[..., :3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices", ["0", "all"])
+def test_plugin_with_rt_hip_devices_renders_through_the_multi_gpu_context(tmp_path, devices):
+    """RT_HIP_DEVICES makes the plug-in create ONE rt_hip_create_multi context (RCCL communicator, gather, assemble, one
+    copy) behind the same blocking render() — on this box 'all' is one GPU, which still takes that whole path."""
+    import os
+
+    import rt_amd
+    from oracle import binding as oracle
+    from tests.conftest import unpack
+
+    ppm = tmp_path / "frame.ppm"
+    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "100x61", "--spp", "4", "--seed", "3", "--frames", "2", "--out", str(ppm), env=dict(os.environ, RT_HIP_DEVICES=devices))
+    assert out.returncode == 0, out.stderr
+    assert "error:" not in out.stderr
+    header = b"P6\n100 61\n255\n"
+    got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(61, 100, 3)
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    want, _, _ = oracle.render(scene.describe(100, 61), 100, 61, seed=3, want_rgb=False)
+    assert np.array_equal(got, unpack(want)[..., :3])
+
+
+@pytest.mark.gpu
+def test_plugin_reports_a_bad_device_list_in_the_reference_error_style(tmp_path):
+    import os
+
+    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "16x8", "--out", str(tmp_path / "x.ppm"), env=dict(os.environ, RT_HIP_DEVICES="0,0"))
+    assert "error: hip_ray_tracer:" in out.stderr and "named twice" in out.stderr
