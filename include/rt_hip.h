@@ -180,7 +180,7 @@ enum
 	 * nothing is hit.  Deterministic: seed, samples_per_pixel and max_bounces are not read; d_rgb_f32 / rgb_f32
 	 * receive the colour before packing.  Partition, gather and assemble work as for the traced frame. */
 	RT_HIP_FLAG_PREVIEW = 1u << 4,
-	/* force the scalar-streamed kernel (testing) */
+	/* force the scalar-streamed kernel (it is what scenes above 1024 primitives get from 32 samples per pixel upwards) */
 	RT_HIP_FLAG_FORCE_STREAMED = 1u << 5
 };
 

@@ -724,7 +724,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
 		// a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
-		const uint32_t variant = choose_kernel(ctx->scene, flags);
+		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params tiles = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);
 		const uint64_t slot_bytes = 4ull * (big_scene ? 2u : 1u) * (static_cast<uint64_t>(tiles.chunks) << tiles.pixels_log2) * 12u;

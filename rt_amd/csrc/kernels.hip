@@ -1069,7 +1069,7 @@ namespace rt_hip
 		}
 	}
 
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
 		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
@@ -1080,7 +1080,11 @@ namespace rt_hip
 			return RT_HIP_KERNEL_SMALL;
 		if (primitives <= resident_max_primitives)
 			return RT_HIP_KERNEL_RESIDENT;
-		return RT_HIP_KERNEL_TILED;
+		// big scenes: the scalar-streamed kernel (no staging, no barriers) wins from about 32 samples per pixel upwards —
+		// 100 000 spheres x 64 spp: 6.46 s against 6.90-7.06 s; 10 000 x 32: 337 against 345 ms; 2 000 x 64: 98 against 108 ms —
+		// and loses 2 % at 8 spp, where a wave holds one item per lane and the tiled kernel's shared staging pays
+		// (profiles/r01/streamed_vs_tiled.txt, profiles/r02/config5_full_size.txt)
+		return samples_per_pixel >= 32u ? RT_HIP_KERNEL_STREAMED : RT_HIP_KERNEL_TILED;
 	}
 
 	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene)
@@ -1132,7 +1136,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene);

@@ -120,7 +120,7 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,
