@@ -17,9 +17,17 @@ HOST_HDR := $(wildcard rt_amd/host/*.hpp) rt_amd/host/host_capi.h rt_amd/host/na
 
 all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so rt_amd/bin/rt_headless oracle
 
+# kernels.hip is compiled twice: the parity contract (contraction off), and RT_HIP_FLAG_FAST's arithmetic
+# (-DRT_HIP_FAST_BUILD -ffp-contract=fast: only launch_render_fast comes out of that one)
+FASTFLAGS := $(filter-out -ffp-contract=off,$(HIPFLAGS)) -ffp-contract=fast -DRT_HIP_FAST_BUILD
+OBJDIR   := build/obj$(NAME)
+
 $(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(HIP_SRC) -L/opt/rocm/lib -lrccl
+	@mkdir -p $(LIBDIR) $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
+	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl
 
 $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -27,7 +35,11 @@ $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 
 # experiment builds for tools/gpu_ab.py: make variant NAME=x DEFS="-DRT_HIP_SOMETHING=1" -> rt_amd/lib/librt_hip_x.so
 variant:
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(HIP_SRC) -L/opt/rocm/lib -lrccl
+	@mkdir -p $(LIBDIR) $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
+	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl
 
 # windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
 HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp

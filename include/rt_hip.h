@@ -181,7 +181,15 @@ enum
 	 * receive the colour before packing.  Partition, gather and assemble work as for the traced frame. */
 	RT_HIP_FLAG_PREVIEW = 1u << 4,
 	/* force the scalar-streamed kernel (it is what scenes above 1024 primitives get from 32 samples per pixel upwards) */
-	RT_HIP_FLAG_FORCE_STREAMED = 1u << 5
+	RT_HIP_FLAG_FORCE_STREAMED = 1u << 5,
+	/* Contract "v2-fast": the kernels built with the hardware's reciprocal / square-root / reciprocal-square-root
+	 * approximations (about 1 ulp each, no correction steps, no range guards) and with multiply-adds contracted — the
+	 * latitude the reference's own build takes (-ffast-math -ffp-contract=fast, meson.build:153-160).  Same random
+	 * streams, same algorithm, same operation order otherwise.  The frame is NOT bit-identical to the oracle's: the
+	 * per-pixel float mean agrees to a few 1e-6 relative wherever no sample's hit/miss decision flipped at a silhouette
+	 * (tests/test_gpu_fast.py states and checks the bounds).  Not available with RT_HIP_FLAG_SM_MATERIALS or
+	 * RT_HIP_FLAG_PREVIEW.  Opt-in; flags == 0 stays the parity contract. */
+	RT_HIP_FLAG_FAST = 1u << 6
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

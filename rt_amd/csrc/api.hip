@@ -675,8 +675,10 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
 	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
-	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED))
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
+	if ((flags & RT_HIP_FLAG_FAST) && (flags & (RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW)))
+		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: RT_HIP_FLAG_FAST applies to mg_ray_tracer's path only (not with RT_HIP_FLAG_SM_MATERIALS / RT_HIP_FLAG_PREVIEW)");
 	if (!ctx->have_scene)
 		return fail(RT_HIP_NO_SCENE, "rt_hip_render_device: no scene uploaded");
 	if (height > 65535u * 2u) // the launch grid's y dimension counts pixel tiles at least two rows high
@@ -738,6 +740,8 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	uint32_t variant = RT_HIP_KERNEL_PREVIEW;
 	if (flags & RT_HIP_FLAG_PREVIEW)
 		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), s);
+	else if (flags & RT_HIP_FLAG_FAST)
+		variant = launch_render_fast(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), ctx->compute_units, ctx->cache, s);
 	else
 		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, ctx->counters.as<device_counters>(), ctx->compute_units, ctx->cache, s);
 	RT_HIP_TRY(hipGetLastError());
@@ -836,7 +840,7 @@ extern "C" rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_s
 
 namespace
 {
-	constexpr uint32_t render_flag_mask = RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED;
+	constexpr uint32_t render_flag_mask = RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST;
 
 	// image_view memory is ordinary pageable host memory (reference src/image.cpp:9-13).  With
 	// RT_HIP_FLAG_PERSISTENT_FRAME it is page-locked on first sight and stays so while the same buffer keeps arriving;
@@ -1040,6 +1044,23 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: %s", e.what());
 	}
 }
+
+#ifdef RT_HIP_REGION_COUNTERS
+// experiment variant only: out[0..12] = runs, out[13..25] = lanes of the most recent launch on this context
+extern "C" rt_hip_status rt_hip_debug_region_counters(rt_hip_ctx* ctx, uint64_t* out)
+{
+	if (!ctx || !out)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_debug_region_counters: NULL argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	RT_HIP_TRY(hipEventSynchronize(ctx->counters_copied));
+	for (unsigned i = 0; i < device_counters::regions; i++)
+	{
+		out[i] = ctx->counters_host->region_runs[i];
+		out[device_counters::regions + i] = ctx->counters_host->region_lanes[i];
+	}
+	return ok();
+}
+#endif
 
 // ---- known-answer entry points --------------------------------------------------------------------------------------
 

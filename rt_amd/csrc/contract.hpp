@@ -39,6 +39,19 @@ namespace rt_hip
 	// expansion otherwise (a wave-uniform branch that is practically never taken), so their results are
 	// BIT-IDENTICAL to __builtin_sqrtf(x), 1.0f / x and 1.0f / __builtin_sqrtf(x) for EVERY input; this is checked
 	// on the device over all 2^32 bit patterns by rt_hip_kat_exhaustive_math (tests/test_gpu_parity.py).
+#ifdef RT_HIP_FAST_BUILD
+	// ---- contract "v2-fast" (RT_HIP_FLAG_FAST; this translation unit is built a second time with RT_HIP_FAST_BUILD and
+	// -ffp-contract=fast) -------------------------------------------------------------------------------------------
+	// The hardware's own approximations, about 1 ulp each, with no correction step and no range guard, and the compiler
+	// free to fuse multiply-adds: what the reference's own build asks of its compiler (-ffast-math -ffp-contract=fast,
+	// meson.build:153-160).  Results are NOT bit-identical to the oracle; tests hold them to a stated tolerance.
+	__device__ __forceinline__ float sqrt_rn_where(float x, bool) { return __builtin_amdgcn_sqrtf(x); }
+	__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }
+	__device__ __forceinline__ float rcp_rn(float x) { return __builtin_amdgcn_rcpf(x); }
+	__device__ __forceinline__ float inv_sqrt_rn(float x) { return __builtin_amdgcn_rsqf(x); }
+	__device__ __forceinline__ float inv_sqrt_in_band(float x) { return __builtin_amdgcn_rsqf(x); }
+	__device__ __forceinline__ float divide(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+#else
 	__device__ __forceinline__ bool in_fast_band(float x) // 2^-60 <= x < 2^60 (positive, finite, normal)
 	{
 		return (__float_as_uint(x) - 0x21800000u) < (0x5D800000u - 0x21800000u);
@@ -127,6 +140,10 @@ namespace rt_hip
 		const float s = sqrt_core(x, h);
 		return rcp_core(s, __builtin_amdgcn_rcpf(s));
 	}
+
+	// a / b, correctly rounded
+	__device__ __forceinline__ float divide(float a, float b) { return a / b; }
+#endif
 
 	// normalize(v) = v * (1 / sqrt(dot(v,v)))
 	__device__ __forceinline__ vec3 normalize(vec3 v)

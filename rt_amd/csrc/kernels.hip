@@ -30,8 +30,17 @@
 //     ("rolling tiles", see render_queue): there a trip costs one scan over all primitives whatever the number of lanes
 //     holding a ray, so lane occupancy is everything.
 // No MFMA: this is intersection arithmetic (subtract / dot / compare / sqrt), not a contraction.
+//
+// This file is compiled TWICE into librt_hip.so: as it stands (the parity contract: -ffp-contract=off, exactly rounded
+// square roots and quotients), and with -DRT_HIP_FAST_BUILD -ffp-contract=fast (RT_HIP_FLAG_FAST: contract.hpp's
+// hardware approximations), where it provides launch_render_fast() and nothing else.
 #include "kernels.hpp"
 #include "contract.hpp"
+
+#ifdef RT_HIP_FAST_BUILD
+#define render_queue render_queue_fast
+#define launch_render launch_render_fast
+#endif
 
 #include "../../include/rt_hip.h"
 
@@ -46,6 +55,20 @@
 #endif
 #ifndef RT_HIP_WAVES_RESIDENT
 #define RT_HIP_WAVES_RESIDENT 7
+#endif
+
+// Region counters (tools/region_profile.py; built only as an experiment variant, never in the product): how often each
+// part of a loop trip runs and with how many lanes — the dynamic side of profiles/r02/isa_trip_breakdown.txt.
+#ifdef RT_HIP_REGION_COUNTERS
+#define RT_HIP_REGION(i)                                                                                               \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		region_runs[i] += 1u;                                                                                          \
+		region_lanes[i] += static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(true)));             \
+	}                                                                                                                  \
+	while (false)
+#else
+#define RT_HIP_REGION(i) ((void)0)
 #endif
 
 namespace rt_hip
@@ -112,7 +135,7 @@ namespace rt_hip
 			if (__builtin_amdgcn_ballot_w64(crosses) != 0)
 			{
 				const float num = dot(n, o) + pl.w;
-				const float t = (-num) / (crosses ? den : 1.0f);
+				const float t = divide(-num, crosses ? den : 1.0f);
 				const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
 				best.t = accept ? t : best.t;
 				best.index = accept ? index : best.index;
@@ -335,6 +358,9 @@ namespace rt_hip
 			}
 			__syncthreads();
 
+#ifdef RT_HIP_REGION_COUNTERS
+			uint32_t region_runs[device_counters::regions] = {}, region_lanes[device_counters::regions] = {};
+#endif
 			constexpr bool ROLLING = NS < 0;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
@@ -423,6 +449,7 @@ namespace rt_hip
 			while (true)
 			{
 				// ---- closest-hit query for every lane that holds a ray (trace(), :160-162) -----------------------------------
+				RT_HIP_REGION(0); // a trip
 				const bool tracing = mode == lane_trace;
 				candidate tiled_planes = { 0.0f, 0u, false };
 				candidate tiled_spheres = { 0.0f, 0u, false };
@@ -460,6 +487,7 @@ namespace rt_hip
 				uint32_t scatter_kind = scatter_lambert;
 				if (tracing)
 				{
+					RT_HIP_REGION(1); // query: probes
 					st.bounces_left--; // `if (!(max_bounces--)) return {}` (:157) is checked when the bounce is made, below
 					st.segments++;
 					uint32_t kind;
@@ -490,13 +518,18 @@ namespace rt_hip
 						{
 #pragma unroll
 							for (int i = 0; i < NS; i++)
+							{
+								if (lanes[i] != 0)
+									RT_HIP_REGION(2); // square-root half of one sphere
 								finish_sphere(best, probes[i], small.geometry[i].w, static_cast<uint32_t>(i), lanes[i]);
+							}
 						}
 						const bool hit = best.have && best.t >= 0.0f;
 						kind = hit ? 1u : 0u;
 						distance = best.t;
 						if (hit)
 						{
+							RT_HIP_REGION(3); // hit: lookups + normal
 							const float4 g = lds_geometry[best.index];
 							shading = lds_shading[best.index];
 							scatter_kind = lds_scatter[best.index];
@@ -516,7 +549,10 @@ namespace rt_hip
 						fetch_hit<SM>(s, st.origin, st.dir, kind, distance, index, normal, shading, scatter_kind);
 					}
 					if (!kind)
+					{
+						RT_HIP_REGION(4); // miss: sky, end of sample
 						end_sample(st.throughput * sky(st.dir.y)); // miss (:163-164)
+					}
 					else
 					{
 						shade = true;
@@ -524,6 +560,7 @@ namespace rt_hip
 						base = normal;
 						if (scatter_kind == scatter_metal)
 						{
+							RT_HIP_REGION(5); // metal: normalise the incoming direction, reflect
 							// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
 							const vec3 v = normalize(st.dir);
 							const float k = 2.0f * dot(v, normal);
@@ -559,6 +596,7 @@ namespace rt_hip
 				};
 				if (!ROLLING && asking != 0)
 				{
+					RT_HIP_REGION(6); // hand-out
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
 					if (mode == lane_free)
 					{
@@ -566,7 +604,10 @@ namespace rt_hip
 						if (slot >= items)
 							mode = lane_retired;
 						else
+						{
+							RT_HIP_REGION(7); // a lane takes an item: pixel coordinates, stream keys
 							take_item(slot, tile_x0, tile_y0);
+						}
 					}
 					next_item += static_cast<uint32_t>(__builtin_popcountll(asking));
 				}
@@ -640,6 +681,7 @@ namespace rt_hip
 				const bool restart = mode == lane_restart;
 				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
 				{
+					RT_HIP_REGION(8); // the fused tail: two draws
 					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
 					uint32_t counter = restart ? sample_counter(st.keys.stride, st.sample) : st.counter;
 					const uint32_t counter_at_start = counter;
@@ -687,6 +729,7 @@ namespace rt_hip
 					}
 					else if (shade)
 					{
+						RT_HIP_REGION(9); // scatter: third draw, unit vector, new direction
 						const bool metal = scatter_kind == scatter_metal;
 						float d2 = next_random_numerator(counter, st.keys);
 						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
@@ -709,6 +752,7 @@ namespace rt_hip
 					}
 					else if (restart)
 					{
+						RT_HIP_REGION(10); // restart: primary ray
 						// worker lambda :189-193 — jittered position, un-project to near and far, build the primary ray
 						float jx = 0x1.0p23f, jy = 0x1.0p23f; // sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing
 						if (st.sample)
@@ -745,6 +789,7 @@ namespace rt_hip
 					}
 					if (shade || restart)
 					{
+						RT_HIP_REGION(11); // normalise the new direction
 						st.counter = counter;
 						if (SM)
 						{
@@ -756,7 +801,10 @@ namespace rt_hip
 					}
 					// absorbed, or the next trace() call would return {} at :157-158: the sample is worth nothing
 					if (shade && (absorbed || st.bounces_left == 0))
+					{
+						RT_HIP_REGION(12); // absorbed or out of bounces
 						end_sample({ 0.0f, 0.0f, 0.0f });
+					}
 				}
 			}
 
@@ -769,8 +817,17 @@ namespace rt_hip
 				fold_tile(slots, tile_x0, tile_y0);
 			}
 			add_segments(counters, st.segments);
+#ifdef RT_HIP_REGION_COUNTERS
+			if (lane == 0)
+				for (unsigned i = 0; i < device_counters::regions; i++)
+				{
+					atomicAdd(&counters->region_runs[i], static_cast<unsigned long long>(region_runs[i]));
+					atomicAdd(&counters->region_lanes[i], static_cast<unsigned long long>(region_lanes[i]));
+				}
+#endif
 		}
 
+#ifndef RT_HIP_FAST_BUILD
 		// ---- preview: reference src/renderers/rasterizer.cpp:24-85 ----------------------------------------------------
 		// One thread per pixel, one ray through the pixel centre; every lane of a wave walks the same primitive, so the
 		// reads below are wave-uniform (scalar loads through the constant cache / L2).  4 bytes written per pixel and a
@@ -1014,6 +1071,8 @@ namespace rt_hip
 				}
 		}
 
+#endif // !RT_HIP_FAST_BUILD
+
 		template <int NS, bool SM>
 		void launch_queue_sm(const frame_params& frame,
 							 const queue_params& queue,
@@ -1032,7 +1091,7 @@ namespace rt_hip
 			{
 				// persistent launch: exactly what the device keeps resident (surplus workgroups would only find the queue dry).
 				// The answer is remembered per context (= per device and host thread of use), per kernel and LDS size.
-				launch_cache::entry& known = cache.persistent[(NS == -1 ? 0 : 2) + (SM ? 1 : 0)];
+				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM)];
 				if (known.lds_bytes != lds_bytes || known.per_cu < 1)
 				{
 					int per_cu = 0;
@@ -1062,13 +1121,16 @@ namespace rt_hip
 						  launch_cache& cache,
 						  hipStream_t stream)
 		{
+#ifndef RT_HIP_FAST_BUILD // (the API refuses RT_HIP_FLAG_FAST together with RT_HIP_FLAG_SM_MATERIALS)
 			if (sm)
 				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 			else
+#endif
 				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
 		}
 	}
 
+#ifndef RT_HIP_FAST_BUILD
 	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
@@ -1122,6 +1184,8 @@ namespace rt_hip
 		q.tiles_y = (local_rows + tile_h - 1u) / tile_h;
 		return q;
 	}
+
+#endif // !RT_HIP_FAST_BUILD
 
 	uint32_t launch_render(const frame_params& frame,
 						   const device_scene& scene,
@@ -1178,6 +1242,7 @@ namespace rt_hip
 		return variant;
 	}
 
+#ifndef RT_HIP_FAST_BUILD
 	void launch_preview(const frame_params& frame, const device_scene& scene, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream)
 	{
 		if (!frame.width || !frame.local_rows)
@@ -1229,4 +1294,5 @@ namespace rt_hip
 	{
 		hipLaunchKernelGGL(kat_exhaustive_math, dim3((1u << 22) / block_threads), dim3(block_threads), 0, stream, d_result);
 	}
+#endif // !RT_HIP_FAST_BUILD
 }

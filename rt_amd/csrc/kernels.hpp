@@ -103,6 +103,10 @@ namespace rt_hip
 		static constexpr unsigned segment_counters = 64;
 		unsigned long long segments[segment_counters];
 		unsigned int next_tile; // head of the tile queue of the big-scene kernels; zeroed with the rest before every launch
+#ifdef RT_HIP_REGION_COUNTERS
+		static constexpr unsigned regions = 13; // experiment variant only (kernels.hip, RT_HIP_REGION)
+		unsigned long long region_runs[regions], region_lanes[regions];
+#endif
 	};
 
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
@@ -116,7 +120,15 @@ namespace rt_hip
 			size_t lds_bytes = 0;
 			int per_cu = 0;
 		};
-		entry persistent[4]; // { tiled, streamed } x { mg, sm scatter table }
+		entry persistent[6]; // { tiled, streamed } x { mg, sm scatter table, fast arithmetic }
+		static constexpr unsigned slot(bool streamed, bool sm)
+		{
+#ifdef RT_HIP_FAST_BUILD
+			return (streamed ? 3u : 0u) + 2u; // (the fast build has no sm scatter table)
+#else
+			return (streamed ? 3u : 0u) + (sm ? 1u : 0u);
+#endif
+		}
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
@@ -133,6 +145,18 @@ namespace rt_hip
 						   uint32_t compute_units, // of the device: the big-scene kernels are launched persistent
 						   launch_cache& cache,
 						   hipStream_t stream);
+
+	// the same with RT_HIP_FLAG_FAST's arithmetic (kernels.hip built with RT_HIP_FAST_BUILD); mg scatter table only
+	uint32_t launch_render_fast(const frame_params& frame,
+								const device_scene& scene,
+								const small_scene& small,
+								uint32_t flags,
+								uint32_t* d_rgba8,
+								float* d_rgb_f32,
+								device_counters* d_counters,
+								uint32_t compute_units,
+								launch_cache& cache,
+								hipStream_t stream);
 
 	// RT_HIP_FLAG_PREVIEW: one ray per pixel, reference src/renderers/rasterizer.cpp:24-85
 	void launch_preview(const frame_params& frame, const device_scene& scene, uint32_t* d_rgba8, float* d_rgb_f32, device_counters* d_counters, hipStream_t stream);

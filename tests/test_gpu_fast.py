@@ -1,0 +1,104 @@
+"""RT_HIP_FLAG_FAST — contract "v2-fast": the stated float tolerance north_star asks for, as an OPT-IN beside the 0-ulp contract.
+
+The fast build of the kernels uses the hardware's v_rcp / v_sqrt / v_rsq approximations (about 1 ulp, no correction, no
+range guards) and lets the compiler contract multiply-adds — the latitude the reference's own build takes
+(-ffast-math -ffp-contract=fast, reference meson.build:153-160).  Random streams, algorithm and operation order are the
+parity contract's, so a FAST frame differs from the exact frame only by
+  (a) rounding: a few 1e-7 .. 1e-6 relative on a pixel's float mean, and
+  (b) the rare sample whose hit/miss (or closest-sphere) decision flips at a silhouette: its whole contribution changes,
+      which moves that pixel's mean by up to 1/spp of the sample's value.
+The bounds below are the tolerance, measured with tools/gpu_fast_probe.py (profiles/r02/fast_vs_exact.txt) and set with
+about 3x margin.  The reference frame is the exact GPU frame, which the parity tests hold to the oracle at 0 ulp.
+"""
+import numpy as np
+import pytest
+
+import rt_amd
+from rt_amd import capi
+
+pytestmark = pytest.mark.gpu
+
+FAST = capi.RT_HIP_FLAG_FAST
+
+
+def compare(tracer, name, width, height, spp, seed=1):
+    pod = rt_amd.Scene.named(name).set_sampling(spp).describe(width, height)
+    exact8, exact, exact_stats = tracer.render(pod, width, height, seed=seed, want_rgb=True)
+    fast8, fast, fast_stats = tracer.render(pod, width, height, seed=seed, flags=FAST, want_rgb=True)
+    assert np.isfinite(fast).all() and (fast >= 0).all() and np.all((fast8 & 0xFF) == 0xFF)
+    rel = np.abs(exact - fast).max(axis=2) / np.maximum(np.abs(exact).max(axis=2), 1e-6)
+    channels = lambda a: np.stack([(a >> s) & 255 for s in (24, 16, 8)], -1).astype(int)
+    lsb = np.abs(channels(exact8) - channels(fast8)).max(axis=2)
+    return {
+        "within_2e-5": float((rel <= 2e-5).mean()),
+        "beyond_1e-3": float((rel > 1e-3).mean()),
+        "median": float(np.median(rel)),
+        "rgba8_within_1": float((lsb <= 1).mean()),
+        "segments": abs(fast_stats["segments"] - exact_stats["segments"]) / exact_stats["segments"],
+        "mean": float(np.abs(fast.mean(axis=(0, 1)) / exact.mean(axis=(0, 1)) - 1).max()),
+        "speedup": exact_stats["render_ms"] / fast_stats["render_ms"],
+        "kernel": fast_stats["kernel"],
+    }
+
+
+@pytest.mark.parametrize(
+    "name,width,height,spp",
+    [
+        ("basic", 1920, 1080, 256),  # the headline
+        ("basic", 1920, 1080, 64),  # BASELINE config 2
+        ("dielectric", 1920, 1080, 256),  # config 3
+        ("basic", 3840, 2160, 256),  # config 4's frame
+    ],
+)
+def test_fast_frames_of_the_baseline_scenes_stay_within_the_stated_tolerance(tracer, name, width, height, spp):
+    r = compare(tracer, name, width, height, spp)
+    print(name, width, height, spp, r)
+    assert r["kernel"] == "small"
+    assert r["within_2e-5"] >= 0.99  # measured 0.9952 .. 0.9984: everything but the pixels with a flipped sample
+    assert r["beyond_1e-3"] <= 0.006  # measured <= 0.0021: the flipped ones
+    assert r["median"] <= 1e-7  # more than half of all pixels are bit-identical (measured 0)
+    assert r["rgba8_within_1"] >= 0.9997  # measured >= 0.99993
+    assert r["segments"] <= 5e-6  # measured <= 7e-7: flips are rare and go both ways
+    assert r["mean"] <= 1e-5  # the image as a whole does not move
+    assert r["speedup"] > 1.05  # it is there to be faster (measured 1.20 .. 1.30)
+
+
+def test_fast_config1_size(tracer):
+    r = compare(tracer, "basic", 256, 256, 1)
+    print(r)
+    assert r["within_2e-5"] >= 0.98 and r["rgba8_within_1"] >= 0.9995 and r["mean"] <= 1e-4
+
+
+def test_fast_on_the_sphere_field_is_the_same_picture_statistically(tracer):
+    """Config 5's scene (a field of 100 000 small spheres, paths of several bounces): silhouettes everywhere, so a good part
+    of the pixels holds a flipped sample; what must hold is that the picture is the same estimate — frame mean, path
+    statistics — and that most packed pixels still agree.  (FAST buys nothing here: the scan is 12 instructions per test
+    either way; 1.01x at full size.)"""
+    r = compare(tracer, "synthetic-100k", 480, 270, 64)
+    print(r)
+    assert r["kernel"] == "streamed"
+    assert r["mean"] <= 5e-3  # measured 1.4e-3 at full size
+    assert r["segments"] <= 2e-3  # measured 5.2e-4
+    assert r["rgba8_within_1"] >= 0.75  # measured 0.88
+    assert r["median"] <= 1e-4  # measured 2.9e-6
+
+
+def test_fast_is_refused_for_the_other_renderers(tracer):
+    pod = rt_amd.Scene.named("dielectric").describe(32, 18)
+    for other in (capi.RT_HIP_FLAG_SM_MATERIALS, capi.RT_HIP_FLAG_PREVIEW):
+        with pytest.raises(rt_amd.RtHipError) as err:
+            tracer.render(pod, 32, 18, flags=FAST | other)
+        assert err.value.status == 5 and "RT_HIP_FLAG_FAST" in str(err.value)
+
+
+def test_fast_goes_through_every_kernel_mode_and_the_multi_gpu_context(tracer):
+    pod = rt_amd.Scene.named("basic").set_sampling(8).describe(200, 120)
+    exact, _, _ = tracer.render(pod, 200, 120, seed=3)
+    for flags, kernel in [(0, "small"), (capi.RT_HIP_FLAG_FORCE_RESIDENT, "resident"), (capi.RT_HIP_FLAG_FORCE_TILED, "tiled"), (capi.RT_HIP_FLAG_FORCE_STREAMED, "streamed")]:
+        fast, _, stats = tracer.render(pod, 200, 120, seed=3, flags=FAST | flags)
+        assert stats["kernel"] == kernel
+        assert (fast == exact).mean() > 0.99, kernel
+    with rt_amd.HipRayTracer(devices=[0, 0, 0], peer_copy=True) as group:
+        fast_group, _, _ = group.render(pod, 200, 120, seed=3, flags=FAST)
+    fast_single, _, _ = tracer.render(pod, 200, 120, seed=3, flags=FAST)
+    assert np.array_equal(fast_group, fast_single)  # FAST is deterministic too, and partition-invariant
