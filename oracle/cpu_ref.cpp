@@ -92,7 +92,9 @@ namespace
 	//   stride   = hash32(k ^ fb) | 1                counter stride (odd)
 	//   counter  = stride * (sample_index * 4096)    before the first draw of a sample (mod 2^32; 4096 draws reserved per sample)
 	//   draw     : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
-	//              x *= 0x846ca68b;  x ^= x >> 16;  u = float(x >> 8) * 2^-24      in [0, 1)
+	//              x *= 0x846ca68b;  u = float(x >> 8) * 2^-24      in [0, 1)
+	//              (the top 24 bits of the last product as they are; lowbias32's closing xorshift would only touch the
+	//              draw's lowest 8 bits)
 	// Two pixels with different strides evaluate their (different) functions at a common counter only at isolated
 	// draws, never along a run.  (Contract v1 drew every pixel from ONE shared hash32 sequence at a hashed offset; a
 	// 1920x1080x256 frame draws 3.6e9 numbers, so most sample windows overlapped another pixel's and some were identical.)
@@ -141,7 +143,6 @@ namespace
 			x = x * 0x7feb352du + function_key;
 			x ^= x >> 15;
 			x *= 0x846ca68bu;
-			x ^= x >> 16;
 			return static_cast<float>(x >> 8) * 0x1.0p-24f;
 		}
 	};

@@ -84,12 +84,12 @@ namespace rt_hip
 	// evaluate both sides on every call).
 #define RT_HIP_RARE_PATH() asm volatile("; rare path: general IEEE expansion" ::: "memory")
 
-	// == __builtin_sqrtf(x) in every lane where `wanted` holds (other lanes get an unspecified finite value)
+	// == __builtin_sqrtf(x) in every lane where `wanted` holds (other lanes get an unspecified value, possibly NaN)
 	__device__ __forceinline__ float sqrt_rn_where(float x, bool wanted)
 	{
 		const bool fast = in_fast_band(x);
 		float h;
-		float s = sqrt_core(fast ? x : 1.0f, h);
+		float s = sqrt_core(x, h); // out of the band: some value (possibly NaN) that is replaced below or never read
 		if (wanted && !fast) // 0, subnormal, huge, infinite, negative or NaN
 		{
 			RT_HIP_RARE_PATH();
@@ -105,8 +105,7 @@ namespace rt_hip
 	__device__ __forceinline__ float rcp_rn(float x)
 	{
 		const bool fast = in_fast_band(__builtin_fabsf(x));
-		const float xs = fast ? x : 1.0f;
-		float q = rcp_core(xs, __builtin_amdgcn_rcpf(xs));
+		float q = rcp_core(x, __builtin_amdgcn_rcpf(x)); // out of the band: replaced below
 		if (!fast)
 		{
 			RT_HIP_RARE_PATH();
@@ -123,7 +122,7 @@ namespace rt_hip
 	{
 		const bool fast = in_fast_band(x);
 		float h;
-		const float s = sqrt_core(fast ? x : 1.0f, h); // in [2^-30, 2^30): inside the reciprocal's band as well
+		const float s = sqrt_core(x, h); // x in the band: s in [2^-30, 2^30), inside the reciprocal's band as well
 		float q = rcp_core(s, __builtin_amdgcn_rcpf(s));
 		if (!fast)
 		{
@@ -182,9 +181,11 @@ namespace rt_hip
 	//   stride    = hash32(k ^ fb) | 1            the pixel's counter stride (odd: m -> stride * m is a bijection)
 	//   counter   = stride * (sample * 4096)      before the first draw of a sample: 4096 draws reserved per sample
 	//   draw      : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
-	//               x *= 0x846ca68b;  x ^= x >> 16;  u = (x >> 8) * 2^-24
-	// i.e. the lowbias32 finaliser with the pixel's key added between its two rounds, walked with the pixel's stride.
-	// For a fixed key the map counter -> x is a bijection of 32-bit words.  The 2^32 counter values are shared by all
+	//               x *= 0x846ca68b;  u = (x >> 8) * 2^-24
+	// i.e. the lowbias32 finaliser with the pixel's key added between its two rounds, walked with the pixel's stride,
+	// and the top 24 bits of the last product taken as they are (lowbias32's closing x ^= x >> 16 only touches the low
+	// half of the word: it would change the draw's lowest 8 bits and cost two instructions).  For a fixed key the map
+	// counter -> x is a bijection of 32-bit words.  The 2^32 counter values are shared by all
 	// pixels (a 4K x 256 spp frame makes 1.5e10 draws), but two pixels with different strides meet only at isolated
 	// counters, never along a run of consecutive draws, and what they compute there goes through different functions.
 	// (Contract v1 drew every pixel from ONE shared sequence at a hashed offset: at 1920x1080x256 samples most sample
@@ -219,13 +220,12 @@ namespace rt_hip
 	constexpr uint32_t draws_per_sample_log2 = 12;
 	__device__ __forceinline__ uint32_t sample_counter(uint32_t stride, uint32_t sample_index) { return stride * (sample_index << draws_per_sample_log2); }
 
-	__device__ __forceinline__ uint32_t keyed_hash32(uint32_t x, uint32_t function_key)
+	__device__ __forceinline__ uint32_t keyed_hash32(uint32_t x, uint32_t function_key) // the draw is the top 24 bits
 	{
 		x ^= x >> 16;
 		x = x * 0x7feb352du + function_key;
 		x ^= x >> 15;
 		x *= 0x846ca68bu;
-		x ^= x >> 16;
 		return x;
 	}
 

@@ -250,7 +250,11 @@ namespace rt_hip
 				out_rgb[o * 3 + 1] = mean.y;
 				out_rgb[o * 3 + 2] = mean.z;
 			}
-			out_rgba[o] = pack_rgba8888({ __builtin_sqrtf(mean.x), __builtin_sqrtf(mean.y), __builtin_sqrtf(mean.z) });
+			// A system-scope store: written through to memory at once.  When the frame is the caller's page-locked back buffer
+			// (rt_hip_render) the pixels then cross PCIe while the rest of the frame is still being traced; an ordinary store
+			// would sit in L2 until the end-of-kernel write-back and put the whole 8 MB transfer behind the kernel
+			// (measured: + 0.10-0.14 ms per frame, profiles/r02/frame_store_ab.txt).  For a frame in HBM it costs nothing.
+			__hip_atomic_store(&out_rgba[o], pack_rgba8888({ __builtin_sqrtf(mean.x), __builtin_sqrtf(mean.y), __builtin_sqrtf(mean.z) }), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 
 		__device__ __forceinline__ void add_segments(device_counters* counters, uint32_t segments)

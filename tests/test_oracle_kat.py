@@ -275,7 +275,6 @@ def _draws(key, stride, counter, n):
         x = (x * np.uint64(0x7FEB352D) + key) & M32
         x ^= x >> np.uint64(15)
         x = (x * np.uint64(0x846CA68B)) & M32
-        x ^= x >> np.uint64(16)
         out[:, j] = (x >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)
     return out
 
