@@ -96,6 +96,8 @@ def main() -> None:
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
+    ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
+    ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` side leg (profiling runs: every render launch of the process is then a step of the drop-in loop)")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
@@ -156,6 +158,9 @@ def main() -> None:
         def step():
             return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
 
+        settle_until = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < settle_until:  # untimed: brings the clocks up from idle; the W warm-up steps follow
+            step()
         for _ in range(args.warmup):
             step()
         fence()
@@ -169,7 +174,7 @@ def main() -> None:
         elapsed = time.perf_counter() - t0
         member0 = tracer.member_stats(0) if n_gpus > 1 else stats
 
-        if n_gpus == 1:
+        if n_gpus == 1 and not args.no_kernel_only:
             # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
             frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
             stream = torch.cuda.current_stream().cuda_stream
@@ -201,6 +206,11 @@ def main() -> None:
                 torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
             return tracers[(frame_maker.frames - 1) % in_flight]
 
+        settle_until = time.perf_counter() + args.settle_ms * 1e-3
+        scratch = torch.empty((frame_maker.padded_rows, args.width), dtype=torch.int32, device=f"cuda:{device}")
+        while time.perf_counter() < settle_until:  # untimed, rank-local (no collective): this rank's own share, over and over
+            tracer.render_device(args.width, args.height, scratch.data_ptr(), seed=args.seed, flags=flags, partition=(rank, world, capi.RT_HIP_DEFAULT_STRIPE_ROWS), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         fence()
@@ -287,6 +297,7 @@ def main() -> None:
                 "arithmetic": "contract v2-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v2 (bit-exact against the oracle)",
                 "parallelism": parallelism,
                 "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight),
+                "clock_settle_ms": args.settle_ms,
             },
             "roofline": roofline,
         }

@@ -3,8 +3,11 @@
 set -o pipefail
 mkdir -p gpurun_out/prof
 export TMPDIR=/tmp
-ARGS="bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 $BENCH_ARGS"
+ARGS="bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 --no-kernel-only $BENCH_ARGS"
 rocprofv3 -L > gpurun_out/prof/counters_list.txt 2>&1 || true
+echo "== the same command without the profiler (this box, for comparison) =="
+timeout -k 10 300 python3 $ARGS > gpurun_out/prof/plain.log 2>&1 || { tail -20 gpurun_out/prof/plain.log; exit 1; }
+tail -1 gpurun_out/prof/plain.log | cut -c1-300
 echo "== kernel trace =="
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace -- python3 $ARGS > gpurun_out/prof/trace.log 2>&1 || { tail -20 gpurun_out/prof/trace.log; exit 1; }
 tail -2 gpurun_out/prof/trace.log
