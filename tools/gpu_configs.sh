@@ -9,5 +9,5 @@ run --steps 20 --warmup 3                                                     # 
 run --steps 20 --warmup 3 --spp 64                                            # config 2: basic 1920x1080x64
 run --steps 10 --warmup 2 --scene dielectric                                  # config 3: dielectric 1920x1080x256
 run --steps 5 --warmup 1 --width 3840 --height 2160                           # config 4's frame on ONE gpu: basic 3840x2160x256
-run --steps 1 --warmup 0 --scene synthetic-100k --spp 64                      # config 5: synthetic 100k spheres 1920x1080x64
+run --steps 1 --warmup 0 --settle-ms 0 --scene synthetic-100k --spp 64                      # config 5: synthetic 100k spheres 1920x1080x64
 run --steps 20 --warmup 3 --width 256 --height 256 --spp 1                    # config 1's size (the reference's CPU-runnable case)
