@@ -225,7 +225,6 @@ namespace rt_hip
 			uint32_t sample;	// index of the sample in flight
 			uint32_t sample_end; // one past the last sample of the chunk in flight
 			uint32_t bounces_left;
-			uint32_t segments;
 		};
 
 		// image row of row `local_row` of this rank's compact buffer (rt_hip_partition).  All branches are wave-uniform.
@@ -257,14 +256,11 @@ namespace rt_hip
 			__hip_atomic_store(&out_rgba[o], pack_rgba8888({ __builtin_sqrtf(mean.x), __builtin_sqrtf(mean.y), __builtin_sqrtf(mean.z) }), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		}
 
-		__device__ __forceinline__ void add_segments(device_counters* counters, uint32_t segments)
+		// `segments` = the wave's count (wave-uniform: kept in a scalar register, one popcount of the tracing lanes per trip)
+		__device__ __forceinline__ void add_segments(device_counters* counters, unsigned long long segments)
 		{
-			unsigned long long total = segments;
-#pragma unroll
-			for (int offset = 32; offset > 0; offset >>= 1)
-				total += __shfl_down(total, offset, 64);
-			if ((threadIdx.x & 63u) == 0 && total)
-				atomicAdd(&counters->segments[(blockIdx.x + blockIdx.y * 7u + (threadIdx.x >> 6)) % device_counters::segment_counters], total);
+			if ((threadIdx.x & 63u) == 0 && segments)
+				atomicAdd(&counters->segments[(blockIdx.x + blockIdx.y * 7u + (threadIdx.x >> 6)) % device_counters::segment_counters], segments);
 		}
 
 		// lookups of the winning primitive from the global per-primitive tables (one indexed read each)
@@ -399,7 +395,11 @@ namespace rt_hip
 				prefetched = fetch_tile(counters);
 
 			lane_state st;
-			st.segments = 0;
+			// path segments traced: counted on the scalar unit (one popcount of the tracing lanes per trip) where scalar
+			// registers are to spare — the 1..4-sphere kernels; 2 more live SGPRs make the others spill — else per lane
+			constexpr bool SCALAR_SEGMENTS = NS >= 1 && NS <= 4;
+			unsigned long long wave_segments = 0;
+			uint32_t lane_segments = 0;
 			uint32_t slot = 0;	  // chunk-sum slot of the item in flight on this lane ([buffer * items +] item)
 			bool holding = false; // rolling: the lane has been given an item that is not yet accounted for as completed
 			// what the lane does in the current trip:
@@ -455,6 +455,8 @@ namespace rt_hip
 				// ---- closest-hit query for every lane that holds a ray (trace(), :160-162) -----------------------------------
 				RT_HIP_REGION(0); // a trip
 				const bool tracing = mode == lane_trace;
+				if (SCALAR_SEGMENTS)
+					wave_segments += static_cast<unsigned>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(tracing)));
 				candidate tiled_planes = { 0.0f, 0u, false };
 				candidate tiled_spheres = { 0.0f, 0u, false };
 				if (NS == -1 && __syncthreads_or(tracing)) // nothing to stream on the very first trip: no lane holds a ray yet
@@ -493,9 +495,11 @@ namespace rt_hip
 				{
 					RT_HIP_REGION(1); // query: probes
 					st.bounces_left--; // `if (!(max_bounces--)) return {}` (:157) is checked when the bounce is made, below
-					st.segments++;
+					if (!SCALAR_SEGMENTS)
+						lane_segments++;
 					uint32_t kind;
 					float distance;
+					uint32_t small_index = 0;
 					if (NS == -1)
 					{
 						uint32_t index;
@@ -531,14 +535,7 @@ namespace rt_hip
 						const bool hit = best.have && best.t >= 0.0f;
 						kind = hit ? 1u : 0u;
 						distance = best.t;
-						if (hit)
-						{
-							RT_HIP_REGION(3); // hit: lookups + normal
-							const float4 g = lds_geometry[best.index];
-							shading = lds_shading[best.index];
-							scatter_kind = lds_scatter[best.index];
-							normal = normalize(ray_at(st.origin, st.dir, best.t) - vec3{ g.x, g.y, g.z }); // (:85)
-						}
+						small_index = best.index; // the lookups of the winning sphere follow below, in the one `hit` region
 					}
 					else
 					{
@@ -561,6 +558,14 @@ namespace rt_hip
 					{
 						shade = true;
 						hit_pos = ray_at(st.origin, st.dir, distance);
+						if (NS > 0)
+						{
+							RT_HIP_REGION(3); // hit: lookups + normal
+							const float4 g = lds_geometry[small_index];
+							shading = lds_shading[small_index];
+							scatter_kind = lds_scatter[small_index];
+							normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
+						}
 						base = normal;
 						if (scatter_kind == scatter_metal)
 						{
@@ -820,7 +825,14 @@ namespace rt_hip
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 				fold_tile(slots, tile_x0, tile_y0);
 			}
-			add_segments(counters, st.segments);
+			if (!SCALAR_SEGMENTS)
+			{
+				wave_segments = lane_segments;
+#pragma unroll
+				for (int offset = 32; offset > 0; offset >>= 1)
+					wave_segments += __shfl_down(wave_segments, offset, 64);
+			}
+			add_segments(counters, wave_segments);
 #ifdef RT_HIP_REGION_COUNTERS
 			if (lane == 0)
 				for (unsigned i = 0; i < device_counters::regions; i++)
