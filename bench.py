@@ -98,6 +98,7 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
     ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` side leg (profiling runs: every render launch of the process is then a step of the drop-in loop)")
+    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` = every process creates one rank of the module's own renderer (rt_hip_create_rank: ncclCommInitRank, the gather inside librt_hip.so, torch.distributed only hands out the id and keeps time); `torch` = torch.distributed.gather + rt_hip_assemble_device.  `library` falls back to `torch` if the communicator cannot be created (and always with --backend gloo)")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
@@ -111,14 +112,14 @@ def main() -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    single_process = world == 1
+    single_process = "RANK" not in os.environ  # not launched by torchrun: one process drives all --gpus devices itself
     if not single_process and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     n_gpus = args.gpus
 
     device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(device)
-    if world > 1:
+    if not single_process:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # "nccl" is RCCL on ROCm
@@ -134,7 +135,7 @@ def main() -> None:
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if not single_process:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -188,26 +189,54 @@ def main() -> None:
             per_frame = (time.perf_counter() - t1) / args.steps
             kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
     else:
-        # ---- one process per GPU (torchrun): stripes -> gather over RCCL -> assemble -> host frame on rank 0 ----
+        # ---- one process per GPU (torchrun): stripes -> ONE gather over RCCL -> assemble -> host frame on rank 0 ----
         in_flight = max(1, args.frames_in_flight)
-        tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
-        tracer = tracers[0]
-        for t in tracers:
-            t.upload(pod)
-        frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
-        host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
-        transport = "torch.distributed gather (backend nccl = RCCL)" if args.backend == "nccl" else "gloo rehearsal"
+        rank_tracer = None
+        if args.gather == "library" and args.backend == "nccl" and in_flight == 1:
+            # every process = one rank of the module's own multi-GPU renderer; torch.distributed only carries the 128-byte id
+            ids = [rt_amd.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            try:
+                rank_tracer = rt_amd.HipRayTracer(device=device, rank=rank, world=world, unique_id=ids[0])
+            except rt_amd.RtHipError as e:
+                print(f"rank {rank}: rt_hip_create_rank failed ({e}); falling back to torch.distributed.gather", file=sys.stderr)
+            created = torch.tensor([1 if rank_tracer is not None else 0], device="cuda")
+            dist.all_reduce(created, op=dist.ReduceOp.MIN)
+            if int(created.item()) == 0 and rank_tracer is not None:
+                rank_tracer.close()
+                rank_tracer = None
+        if rank_tracer is not None:
+            tracers = [rank_tracer]
+            tracer = rank_tracer
+            tracer.upload(pod)
+            transport = "inside librt_hip.so: ncclCommInitRank + one ncclGather to rank 0 (torch.distributed only hands out the id)"
+            back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
+            render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+            padded = rt_amd.padded_local_rows(args.height, world)
 
-        def step():
-            frame = frame_maker.render(seed=args.seed, flags=flags)
-            if frame is not None:
-                host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
-            if in_flight == 1:
-                torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
-            return tracers[(frame_maker.frames - 1) % in_flight]
+            def step():  # collective and blocking: rank 0 returns with the frame in its back buffer
+                tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)
+                return tracer
+        else:
+            tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
+            tracer = tracers[0]
+            for t in tracers:
+                t.upload(pod)
+            frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
+            padded = frame_maker.padded_rows
+            host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
+            transport = "torch.distributed gather (backend nccl = RCCL)" if args.backend == "nccl" else "gloo rehearsal"
+
+            def step():
+                frame = frame_maker.render(seed=args.seed, flags=flags)
+                if frame is not None:
+                    host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
+                if in_flight == 1:
+                    torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
+                return tracers[(frame_maker.frames - 1) % in_flight]
 
         settle_until = time.perf_counter() + args.settle_ms * 1e-3
-        scratch = torch.empty((frame_maker.padded_rows, args.width), dtype=torch.int32, device=f"cuda:{device}")
+        scratch = torch.empty((padded, args.width), dtype=torch.int32, device=f"cuda:{device}")
         while time.perf_counter() < settle_until:  # untimed, rank-local (no collective): this rank's own share, over and over
             tracer.render_device(args.width, args.height, scratch.data_ptr(), seed=args.seed, flags=flags, partition=(rank, world, capi.RT_HIP_DEFAULT_STRIPE_ROWS), stream=torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
@@ -269,7 +298,7 @@ def main() -> None:
             },
         }
         synthetic = args.scene.startswith("synthetic")
-        if n_gpus == 1:
+        if n_gpus == 1 and single_process:
             parallelism = "1 GPU"
         elif single_process:
             parallelism = f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, {transport}, device assemble, one D2H"
@@ -309,7 +338,7 @@ def main() -> None:
             line["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.cpu_baseline_seconds)
         print(json.dumps(line), flush=True)
 
-    if world > 1:
+    if not single_process:
         dist.barrier()
         dist.destroy_process_group()
         for t in tracers:

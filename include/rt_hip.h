@@ -236,6 +236,20 @@ enum
 	RT_HIP_MULTI_PEER_COPY = 1u << 0
 };
 rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags);
+
+/*
+ * The same renderer with ONE PROCESS PER GPU (how `torchrun` launches a job): every process creates one rank of it.
+ *   rt_hip_unique_id   on one process: a fresh RCCL id (rccl.h: ncclGetUniqueId); hand the bytes to every rank by any means
+ *                      (the harness broadcasts them with torch.distributed).
+ *   rt_hip_create_rank on every process, collectively (rccl.h: ncclCommInitRank): rank `rank` of `world` on `device`.
+ * rt_hip_render() on such a context is collective too: every rank passes the same scene, size, seed and flags and renders
+ * rt_hip_partition{rank, world, 8}; the stripes are gathered on rank 0 with the same single ncclGather; rank 0 assembles
+ * and fills ITS caller's `pixels_rgba8888` (the other ranks may pass NULL and return once their stripes are sent).
+ * rgb_f32 must be NULL or non-NULL on all ranks alike.  Nothing in the reference corresponds (it is one process).
+ */
+#define RT_HIP_UNIQUE_ID_BYTES 128
+rt_hip_status rt_hip_unique_id(char out_id[RT_HIP_UNIQUE_ID_BYTES]);
+rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES]);
 /* number of members of a context (1 for rt_hip_create) and the device of member `rank` */
 rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count);
 rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device);

@@ -112,6 +112,8 @@ RT_HIP_SYMBOLS = [
     ("rt_hip_create", C.c_int, [C.POINTER(C.c_void_p), C.c_int]),
     ("rt_hip_destroy", None, [C.c_void_p]),
     ("rt_hip_create_multi", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_uint32]),
+    ("rt_hip_unique_id", C.c_int, [C.c_char * 128]),
+    ("rt_hip_create_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char * 128]),
     ("rt_hip_member_count", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("rt_hip_member_device", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("rt_hip_member_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(RtHipStats)]),

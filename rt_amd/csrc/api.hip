@@ -149,6 +149,9 @@ struct rt_hip_ctx
 	// The context the caller holds is member 0 (the root); it owns members 1 .. n-1, one per further device.
 	bool multi = false;
 	bool peer_copy = false;			  // RT_HIP_MULTI_PEER_COPY
+	// the renderer's ranks: `world` in all, of which this process holds first_rank .. first_rank + members - 1
+	// (rt_hip_create_multi: all of them; rt_hip_create_rank: exactly one, the others live in other processes)
+	uint32_t world = 1, first_rank = 0;
 	std::vector<rt_hip_ctx*> peers;	  // members 1 .. n-1
 	std::vector<ncclComm_t> comms;	  // one communicator per member, rank order (empty with peer_copy)
 	device_buffer stripes_rgba, stripes_rgb;   // this member's compact stripe buffers (the gather's send side)
@@ -325,6 +328,8 @@ extern "C" rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* de
 			return st;
 		root->multi = true;
 		root->peer_copy = peer_copy;
+		root->world = static_cast<uint32_t>(n_devices);
+		root->first_rank = 0;
 		for (int r = 1; r < n_devices; r++)
 		{
 			rt_hip_ctx* member = nullptr;
@@ -375,6 +380,52 @@ extern "C" rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* de
 	catch (const std::exception& e)
 	{
 		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_multi: %s", e.what());
+	}
+}
+
+extern "C" rt_hip_status rt_hip_unique_id(char out_id[RT_HIP_UNIQUE_ID_BYTES])
+{
+	static_assert(sizeof(ncclUniqueId) == RT_HIP_UNIQUE_ID_BYTES, "rt_hip.h must match rccl.h's ncclUniqueId");
+	if (!out_id)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_unique_id: NULL argument");
+	ncclUniqueId id;
+	RT_HIP_TRY_NCCL(ncclGetUniqueId(&id));
+	std::memcpy(out_id, &id, sizeof(id));
+	return ok();
+}
+
+extern "C" rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES])
+{
+	if (!out_ctx)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_rank: out_ctx is NULL");
+	*out_ctx = nullptr;
+	if (!id || world < 1 || world > 4096 || rank < 0 || rank >= world)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_rank: invalid rank %d of %d", rank, world);
+	try
+	{
+		rt_hip_ctx* ctx = nullptr;
+		if (const rt_hip_status st = rt_hip_create(&ctx, device))
+			return st;
+		ctx->multi = true;
+		ctx->world = static_cast<uint32_t>(world);
+		ctx->first_rank = static_cast<uint32_t>(rank);
+		ncclUniqueId unique;
+		std::memcpy(&unique, id, sizeof(unique));
+		ctx->comms.assign(1, nullptr);
+		// collective: returns when every rank of the renderer has called it (rccl.h: ncclCommInitRank)
+		const ncclResult_t res = ncclCommInitRank(&ctx->comms[0], world, unique, rank);
+		if (res != ncclSuccess)
+		{
+			ctx->comms.clear();
+			rt_hip_destroy(ctx);
+			return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_rank: ncclCommInitRank(rank %d of %d) failed: %s", rank, world, ncclGetErrorString(res));
+		}
+		*out_ctx = ctx;
+		return ok();
+	}
+	catch (const std::exception& e)
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_create_rank: %s", e.what());
 	}
 }
 
@@ -926,8 +977,11 @@ namespace
 							   float* rgb_f32,
 							   rt_hip_stats* stats)
 	{
-		const int n = 1 + static_cast<int>(root->peers.size());
-		const uint32_t world = static_cast<uint32_t>(n);
+		const int n = 1 + static_cast<int>(root->peers.size()); // members in this process
+		const uint32_t world = root->world;						 // ranks in all
+		const bool have_root = root->first_rank == 0;			 // rank 0 assembles the frame and hands it to its caller
+		if (have_root && !pixels_rgba8888)
+			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: rank 0 needs the frame buffer");
 		const rt_hip_partition whole = { 0, world, RT_HIP_DEFAULT_STRIPE_ROWS };
 		uint32_t padded_rows = 0;
 		if (const rt_hip_status st = rt_hip_padded_local_rows(height, &whole, &padded_rows))
@@ -935,7 +989,7 @@ namespace
 		const size_t pixels = static_cast<size_t>(width) * height;
 		const size_t stripe_pixels = static_cast<size_t>(padded_rows) * width; // what every member sends
 		if (stripe_pixels * 3u > 0x7FFFFFFFull)
-			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: a %ux%u frame over %d devices exceeds the gather's element count", width, height, n);
+			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: a %ux%u frame over %u ranks exceeds the gather's element count", width, height, world);
 
 		// 1. every member: scene resident (re-uploaded only when the host columns changed), its share of the frame
 		//    launched on its own stream.  Nothing here waits for a GPU, so the members run concurrently.
@@ -947,17 +1001,20 @@ namespace
 			RT_HIP_TRY(member->stripes_rgba.reserve(stripe_pixels * sizeof(uint32_t)));
 			if (rgb_f32)
 				RT_HIP_TRY(member->stripes_rgb.reserve(stripe_pixels * 3 * sizeof(float)));
-			const rt_hip_partition part = { static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
+			const rt_hip_partition part = { root->first_rank + static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
 			if (const rt_hip_status st = rt_hip_render_device(member, width, height, seed, flags & render_flag_mask, &part, member->stripes_rgba.as<uint32_t>(), rgb_f32 ? member->stripes_rgb.as<float>() : nullptr, member->stream))
 				return st;
 			RT_HIP_TRY(hipEventRecord(member->stripes_ready, member->stream));
 		}
 
-		// 2. ONE gather of the compact stripe buffers to the root, rank order
+		// 2. ONE gather of the compact stripe buffers to rank 0, rank order
 		RT_HIP_TRY(hipSetDevice(root->device));
-		RT_HIP_TRY(root->gathered_rgba.reserve(stripe_pixels * sizeof(uint32_t) * world));
-		if (rgb_f32)
-			RT_HIP_TRY(root->gathered_rgb.reserve(stripe_pixels * 3 * sizeof(float) * world));
+		if (have_root)
+		{
+			RT_HIP_TRY(root->gathered_rgba.reserve(stripe_pixels * sizeof(uint32_t) * world));
+			if (rgb_f32)
+				RT_HIP_TRY(root->gathered_rgb.reserve(stripe_pixels * 3 * sizeof(float) * world));
+		}
 		if (root->peer_copy)
 		{
 			for (int r = 0; r < n; r++)
@@ -979,16 +1036,26 @@ namespace
 			for (int r = 0; r < n && res == ncclSuccess; r++)
 			{
 				rt_hip_ctx* member = member_of(root, r);
-				res = ncclGather(member->stripes_rgba.ptr, r == 0 ? root->gathered_rgba.ptr : nullptr, stripe_pixels, ncclUint32, 0, root->comms[static_cast<size_t>(r)], member->stream);
+				const bool receives = have_root && r == 0;
+				res = ncclGather(member->stripes_rgba.ptr, receives ? root->gathered_rgba.ptr : nullptr, stripe_pixels, ncclUint32, 0, root->comms[static_cast<size_t>(r)], member->stream);
 				if (res == ncclSuccess && rgb_f32)
-					res = ncclGather(member->stripes_rgb.ptr, r == 0 ? root->gathered_rgb.ptr : nullptr, stripe_pixels * 3, ncclFloat, 0, root->comms[static_cast<size_t>(r)], member->stream);
+					res = ncclGather(member->stripes_rgb.ptr, receives ? root->gathered_rgb.ptr : nullptr, stripe_pixels * 3, ncclFloat, 0, root->comms[static_cast<size_t>(r)], member->stream);
 			}
 			const ncclResult_t end = ncclGroupEnd();
 			RT_HIP_TRY_NCCL(res);
 			RT_HIP_TRY_NCCL(end);
 		}
 
-		// 3. root: de-interleave into the frame, one copy to the host
+		if (!have_root)
+		{
+			// a rank of a renderer whose rank 0 lives in another process: done when its stripes have been sent
+			RT_HIP_TRY(hipStreamSynchronize(root->stream));
+			if (stats)
+				return rt_hip_stats_fetch(root, stats);
+			return ok();
+		}
+
+		// 3. rank 0: de-interleave into the frame, one copy to the host
 		RT_HIP_TRY(hipSetDevice(root->device));
 		RT_HIP_TRY(root->frame_rgba.reserve(pixels * sizeof(uint32_t)));
 		launch_assemble(width, height, world, RT_HIP_DEFAULT_STRIPE_ROWS, padded_rows, root->gathered_rgba.as<uint32_t>(), root->frame_rgba.as<uint32_t>(), root->stream);
@@ -1039,7 +1106,7 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 									   float* rgb_f32,
 									   rt_hip_stats* stats)
 {
-	if (!ctx || !scene || !pixels_rgba8888)
+	if (!ctx || !scene || (!pixels_rgba8888 && !(ctx->multi && ctx->first_rank != 0)))
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: NULL argument");
 	if (!width || !height)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: empty frame %ux%u", width, height);
@@ -1050,7 +1117,8 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 	try
 	{
 		RT_HIP_TRY(hipSetDevice(ctx->device));
-		track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0);
+		if (pixels_rgba8888)
+			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0);
 		if (ctx->multi)
 			return render_multi(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats);
 

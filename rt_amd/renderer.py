@@ -34,6 +34,13 @@ def padded_local_rows(height: int, world: int, stripe_rows: int = capi.RT_HIP_DE
     return out.value
 
 
+def unique_id() -> bytes:
+    """A fresh id for a renderer with one process per GPU (rt_hip_unique_id): create it once, give it to every rank."""
+    buf = (C.c_char * 128)()
+    check(capi.hip_lib().rt_hip_unique_id(buf))
+    return bytes(buf.raw)
+
+
 def device_count() -> int:
     n = C.c_int()
     check(capi.hip_lib().rt_hip_device_count(C.byref(n)))
@@ -45,9 +52,19 @@ class HipRayTracer:
     scene replicated, row stripes dealt round-robin, one RCCL gather to devices[0], one copy to the host.
     `peer_copy`: move the stripes with hipMemcpyPeerAsync instead of RCCL (allows a device to appear twice: tests)."""
 
-    def __init__(self, device: int = 0, devices: list[int] | None = None, peer_copy: bool = False):
+    def __init__(self, device: int = 0, devices: list[int] | None = None, peer_copy: bool = False, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None):
+        """`rank`, `world`, `unique_id`: one rank of a renderer with one process per GPU (rt_hip_create_rank; collective).
+        The id comes from `unique_id()` on one process and must reach every rank unchanged."""
         self._lib = capi.hip_lib()
         self._ctx = C.c_void_p()
+        if rank is not None:
+            assert world is not None and unique_id is not None and len(unique_id) == 128
+            check(self._lib.rt_hip_create_rank(C.byref(self._ctx), device, rank, world, (C.c_char * 128).from_buffer_copy(unique_id)))
+            self.device = device
+            self.devices = [device]
+            self.rank, self.world = rank, world
+            return
+        self.rank, self.world = 0, 1
         if devices is None:
             check(self._lib.rt_hip_create(C.byref(self._ctx), device))
             self.device = device
@@ -76,6 +93,11 @@ class HipRayTracer:
         """rt_hip_render: returns (rgba8 uint32[H, W], rgb float32[H, W, 3] or None, stats dict).
 
         `out`: a uint32[H, W] array to render into (like rt's persistent back buffer); a fresh one otherwise."""
+        if self.rank != 0:  # a rank whose rank 0 lives in another process renders and sends; it has no frame of its own
+            stats = RtHipStats()
+            rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
+            check(self._lib.rt_hip_render(self._ctx, C.byref(scene), None, width, height, seed, flags, rgb.ctypes.data if rgb is not None else None, C.byref(stats)))
+            return None, None, stats.as_dict()
         rgba = out if out is not None else np.empty((height, width), dtype=np.uint32)
         assert rgba.dtype == np.uint32 and rgba.shape == (height, width) and rgba.flags.c_contiguous
         rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None

@@ -74,3 +74,19 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_step():
     line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
     assert "one process per GPU" in line["config"]["parallelism"] and line["config"]["frames_in_flight"] == 1
+
+
+@pytest.mark.gpu
+def test_one_rank_under_torchrun_takes_the_library_rank_path():
+    """What the driver launches for N > 1, with N = 1: torch.distributed.run, RCCL process group, the 128-byte id broadcast,
+    rt_hip_create_rank (ncclCommInitRank), the collective rt_hip_render — everything but the second GPU."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    line = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--spp", "32", "--cpu-baseline-seconds", "0"], launcher=launcher)
+    assert line["n_gpus"] == 1 and "ncclCommInitRank" in line["config"]["parallelism"]
+    assert line["value"] == pytest.approx(1920 * 1080 * 32 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    assert 0 < line["roofline"]["frac"] < 1

@@ -134,3 +134,21 @@ def test_two_contexts_on_one_device_used_from_two_host_threads(tracer):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_a_world_of_one_rank_goes_through_ncclcomminitrank():
+    """One process per GPU (rt_hip_create_rank): with a single rank everything but the second process is real — the id
+    from ncclGetUniqueId, ncclCommInitRank, the gather, assemble, the copy.  (Two ranks cannot share this box's one GPU:
+    RCCL refuses; the rank arithmetic is the multi-member path's, tested above with 2..8 members.)"""
+    width, height, seed = 150, 90, 8
+    pod = _scene("dielectric", 3).describe(width, height)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    uid = rt_amd.unique_id()
+    assert len(uid) == 128 and uid != rt_amd.unique_id()
+    with rt_amd.HipRayTracer(device=0, rank=0, world=1, unique_id=uid) as tracer:
+        for _ in range(2):
+            rgba, rgb, stats = tracer.render(pod, width, height, seed=seed, want_rgb=True)
+            assert np.array_equal(rgba, want_rgba) and np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32))
+            assert stats["segments"] == want_stats["segments"]
+    with pytest.raises(rt_amd.RtHipError, match="invalid rank"):
+        rt_amd.HipRayTracer(device=0, rank=2, world=2, unique_id=uid)
