@@ -411,6 +411,35 @@ namespace rt_hip
 			// all items of a tile are in: fold the chunk sums of each pixel in chunk order and write it (:195-200)
 			const auto fold_tile = [&](const float* sums, uint32_t x0, uint32_t y0)
 			{
+				if (!ROLLING && (3u << q.pixels_log2) <= 64u) // wave-uniform
+				{
+					// Small tiles (<= 16 pixels: from 113 samples per pixel upwards) are folded one CHANNEL per lane — lane
+					// = channel * P + pixel — so that the chunk loop, the division by the sample count and the square
+					// root are issued once for all three channels instead of three times by a third of the lanes.  Per
+					// channel the arithmetic is what finish_pixel does; the packed bytes then meet in the pixel's lane.
+					const uint32_t channel = lane >> q.pixels_log2;
+					const uint32_t pixel = lane & ((1u << q.pixels_log2) - 1u);
+					const uint32_t lx = x0 + (pixel & (tile_w - 1u));
+					const uint32_t ly = y0 + (pixel >> q.tile_w_log2);
+					const bool live = channel < 3u && lx < p.width && ly < p.local_rows;
+					float sum = 0.0f;
+					if (live)
+					{
+						sum = sums[pixel * 3u + channel];
+						for (uint32_t c = 1; c < q.chunks; c++)
+							sum = sum + sums[((c << q.pixels_log2) + pixel) * 3u + channel];
+					}
+					const float mean = sum / static_cast<float>(p.samples_per_pixel);
+					const size_t o = static_cast<size_t>(ly) * p.width + lx;
+					if (live && out_rgb)
+						out_rgb[o * 3u + channel] = mean;
+					const uint32_t byte = static_cast<uint32_t>(clamp01(__builtin_sqrtf(mean)) * 255.99999f);
+					const uint32_t green = __shfl(byte, lane + (1u << q.pixels_log2), 64);
+					const uint32_t blue = __shfl(byte, lane + (2u << q.pixels_log2), 64);
+					if (live && channel == 0u)
+						__hip_atomic_store(&out_rgba[o], (byte << 24u) | (green << 16u) | (blue << 8u) | 255u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					return;
+				}
 				for (uint32_t pixel = lane; pixel < (1u << q.pixels_log2); pixel += 64u)
 				{
 					const uint32_t lx = x0 + (pixel & (tile_w - 1u));
