@@ -528,3 +528,33 @@ def test_bad_arguments_are_refused(tracer):
     # the context is still usable after refused calls
     rgba, _, _ = tracer.render(pod, 16, 16)
     assert rgba.shape == (16, 16)
+
+
+# ---- the caller's back buffer ------------------------------------------------------------------------------------------------
+def test_rendering_straight_into_the_page_locked_back_buffer(tracer):
+    """RT_HIP_FLAG_PERSISTENT_FRAME (what the plug-in passes): the buffer is moved to the GPU's NUMA node, page-locked, mapped,
+    and the kernel stores finished pixels straight into it.  Same frames as the staged path; survives a change of size, of
+    buffer, a forget, and going back to an unflagged call."""
+    pod = rt_amd.Scene.named("basic").set_sampling(6).describe(333, 187)
+    want, _, _ = oracle.render(pod, 333, 187, seed=2, want_rgb=False)
+    small = rt_amd.Scene.named("basic").set_sampling(2).describe(64, 40)
+    want_small, _, _ = oracle.render(small, 64, 40, seed=3, want_rgb=False)
+    flag = capi.RT_HIP_FLAG_PERSISTENT_FRAME
+    back = np.full((187, 333), 0xDEADBEEF, dtype=np.uint32)
+    for _ in range(3):
+        got, _, stats = tracer.render(pod, 333, 187, seed=2, flags=flag, out=back)
+        assert got is back and np.array_equal(back, want) and stats["readback_ms"] < 5.0
+    other = np.zeros((40, 64), dtype=np.uint32)  # a "resize": new buffer, new size
+    tracer.render(small, 64, 40, seed=3, flags=flag, out=other)
+    assert np.array_equal(other, want_small)
+    tracer.forget_frame()
+    tracer.forget_frame()  # harmless twice
+    tracer.render(small, 64, 40, seed=3, flags=flag, out=other)
+    assert np.array_equal(other, want_small)
+    back[:] = 0
+    tracer.render(pod, 333, 187, seed=2, out=back)  # no flag: staged copy, registration dropped
+    assert np.array_equal(back, want)
+    view = np.zeros((187 + 2, 333), dtype=np.uint32)[1:-1]  # a buffer that does not start on a page boundary
+    tracer.render(pod, 333, 187, seed=2, flags=flag, out=view)
+    assert np.array_equal(view, want)
+    tracer.forget_frame()

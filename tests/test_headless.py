@@ -117,3 +117,18 @@ def test_plugin_reports_a_bad_device_list_in_the_reference_error_style(tmp_path)
 
     out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "16x8", "--out", str(tmp_path / "x.ppm"), env=dict(os.environ, RT_HIP_DEVICES="0,0"))
     assert "error: hip_ray_tracer:" in out.stderr and "named twice" in out.stderr
+
+
+def test_device_list_errors_are_reported_without_a_gpu(tmp_path):
+    """RT_HIP_DEVICES is parsed by the plug-in and checked by rt_hip_create_multi before any device is touched, so the
+    messages can be checked on a box without a GPU as well; the frame stays the caller's pre-cleared black."""
+    import os
+
+    for devices, message in [("0,0", "named twice"), ("0,1,x", None), ("", None)]:
+        ppm = tmp_path / "x.ppm"
+        out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "16x8", "--out", str(ppm), env=dict(os.environ, RT_HIP_DEVICES=devices))
+        if message:
+            assert "error: hip_ray_tracer:" in out.stderr and message in out.stderr, out.stderr
+        if "error: hip_ray_tracer:" in out.stderr:
+            data = ppm.read_bytes()
+            assert set(data[len(b"P6\n16 8\n255\n") :]) == {0}
