@@ -558,3 +558,41 @@ def test_rendering_straight_into_the_page_locked_back_buffer(tracer):
     tracer.render(pod, 333, 187, seed=2, flags=flag, out=view)
     assert np.array_equal(view, want)
     tracer.forget_frame()
+
+
+# ---- the random streams at full frame size ---------------------------------------------------------------------------------------
+def test_noise_statistics_at_1080p_match_independent_generators(tracer):
+    """contract v1's streams overlapped at full frame size and the statistical test only looked at small
+    frames.  Here the WHOLE 1920x1080 frame at 16 spp (33 M sample streams) is compared with the reference-faithful model —
+    one std::mt19937 per host thread (reference src/random.cpp:9-26) — against a 1024 spp image as ground truth:
+      * per-pixel error variance of the two 16 spp images must agree (same estimator, same noise);
+      * errors of NEIGHBOURING pixels must be as uncorrelated under the counter streams as under independent engines:
+        the variance of 4x4 block means is 1/16 of the pixel variance exactly when the 16 errors are uncorrelated
+        (streams shared between pixels, as in v1, push the ratio up)."""
+    import os
+
+    if len(os.sched_getaffinity(0)) < 32:
+        pytest.skip("the mt19937 model of a 1080p x 16 spp frame wants a many-core host (the GPU boxes have 256 threads)")
+    width, height = 1920, 1080
+    scene = rt_amd.Scene.named("basic")
+    truth = tracer.render(scene.set_sampling(1024).describe(width, height), width, height, seed=99, want_rgb=True)[1].astype(np.float64)
+    pod = scene.set_sampling(16).describe(width, height)
+    ours = tracer.render(pod, width, height, seed=5, want_rgb=True)[1].astype(np.float64)
+    _, model, _ = oracle.render_mt19937(pod, width, height, fixed_seed=77, want_rgb=True)
+    model = model.astype(np.float64)
+
+    def noise(img):
+        err = (img - truth)[..., 0]  # red channel: ground, sky and both spheres all show in it
+        pixel_var = (err**2).mean()
+        blocks = err.reshape(height // 4, 4, width // 4, 4).mean(axis=(1, 3))
+        return pixel_var, (blocks**2).mean() * 16.0 / pixel_var, err
+
+    var_ours, ratio_ours, err_ours = noise(ours)
+    var_model, ratio_model, err_model = noise(model)
+    print(f"pixel error variance: counter streams {var_ours:.3e}, mt19937 model {var_model:.3e}; block ratio {ratio_ours:.4f} vs {ratio_model:.4f}")
+    assert var_ours == pytest.approx(var_model, rel=0.03)
+    assert ratio_ours == pytest.approx(ratio_model, abs=0.03)  # both ~1.06 (the 1024 spp reference's own noise is shared by a block's pixels... and is tiny)
+    assert 0.9 < ratio_ours < 1.2
+    # horizontal and vertical neighbours: correlation of the errors
+    for a, b in ((err_ours[:, 1:], err_ours[:, :-1]), (err_ours[1:], err_ours[:-1])):
+        assert abs(np.corrcoef(a.ravel(), b.ravel())[0, 1]) < 0.01
