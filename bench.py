@@ -99,6 +99,7 @@ def main() -> None:
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
     ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` side leg (profiling runs: every render launch of the process is then a step of the drop-in loop)")
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` = every process creates one rank of the module's own renderer (rt_hip_create_rank: ncclCommInitRank, the gather inside librt_hip.so, torch.distributed only hands out the id and keeps time); `torch` = torch.distributed.gather + rt_hip_assemble_device.  `library` falls back to `torch` if the communicator cannot be created (and always with --backend gloo)")
+    ap.add_argument("--direct-frame", action="store_true", help="single-process N > 1 only: RT_HIP_MULTI_DIRECT_FRAME — no gather, every GPU stores its pixels straight into the page-locked back buffer")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
@@ -148,11 +149,13 @@ def main() -> None:
             tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
             transport = None
         elif args.same_device:
-            tracer = rt_amd.HipRayTracer(devices=[device] * n_gpus, peer_copy=True)
+            tracer = rt_amd.HipRayTracer(devices=[device] * n_gpus, peer_copy=True, direct_frame=args.direct_frame)
             transport = "peer copies on one device (rehearsal)"
         else:
-            tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)))
+            tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)), direct_frame=args.direct_frame)
             transport = "RCCL: ncclCommInitAll + one ncclGather to device 0"
+        if n_gpus > 1 and args.direct_frame:
+            transport = "NO gather (RT_HIP_MULTI_DIRECT_FRAME): every GPU stores its pixels straight into the mapped back buffer"
         back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
         render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
 

@@ -233,7 +233,14 @@ enum
 	RT_HIP_MULTI_NONE = 0u,
 	/* move the stripes with hipMemcpyPeerAsync instead of RCCL.  RCCL refuses a communicator that names a device twice;
 	 * with this flag `devices` may (a one-GPU box can then exercise the whole multi-member path: tests). */
-	RT_HIP_MULTI_PEER_COPY = 1u << 0
+	RT_HIP_MULTI_PEER_COPY = 1u << 0,
+	/* no gather: when the caller's back buffer is page-locked (RT_HIP_FLAG_PERSISTENT_FRAME) every member's kernel stores
+	 * its pixels straight into their image rows of that buffer, each over its own PCIe link, and rt_hip_render returns when
+	 * the last member's launch is done — no stripe buffers, no collective, no de-interleave, no copy.  What a frame of a
+	 * few milliseconds wants on 8 GPUs, where gather + assemble + copy cost as much as a member's share of the tracing.
+	 * Opt-in: the documented default remains the single RCCL gather.  (Calls without the flag, or that ask for the float
+	 * mean, take the gathered way.) */
+	RT_HIP_MULTI_DIRECT_FRAME = 1u << 1
 };
 rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags);
 

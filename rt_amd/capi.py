@@ -26,6 +26,7 @@ RT_HIP_FLAG_PREVIEW = 1 << 4
 RT_HIP_FLAG_FORCE_STREAMED = 1 << 5
 RT_HIP_FLAG_FAST = 1 << 6
 RT_HIP_MULTI_PEER_COPY = 1 << 0
+RT_HIP_MULTI_DIRECT_FRAME = 1 << 1
 KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview", 5: "streamed"}
 
 STATUS_NAMES = {

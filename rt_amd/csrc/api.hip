@@ -149,6 +149,7 @@ struct rt_hip_ctx
 	// The context the caller holds is member 0 (the root); it owns members 1 .. n-1, one per further device.
 	bool multi = false;
 	bool peer_copy = false;			  // RT_HIP_MULTI_PEER_COPY
+	bool direct_frame = false;		  // RT_HIP_MULTI_DIRECT_FRAME
 	// the renderer's ranks: `world` in all, of which this process holds first_rank .. first_rank + members - 1
 	// (rt_hip_create_multi: all of them; rt_hip_create_rank: exactly one, the others live in other processes)
 	uint32_t world = 1, first_rank = 0;
@@ -309,7 +310,7 @@ extern "C" rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* de
 	*out_ctx = nullptr;
 	if (n_devices < 1 || n_devices > 64)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_create_multi: %d devices (1 .. 64 supported)", n_devices);
-	if (multi_flags & ~static_cast<uint32_t>(RT_HIP_MULTI_PEER_COPY))
+	if (multi_flags & ~static_cast<uint32_t>(RT_HIP_MULTI_PEER_COPY | RT_HIP_MULTI_DIRECT_FRAME))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_create_multi: unknown flag bits 0x%x", multi_flags);
 	const bool peer_copy = (multi_flags & RT_HIP_MULTI_PEER_COPY) != 0;
 	try
@@ -328,6 +329,7 @@ extern "C" rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* de
 			return st;
 		root->multi = true;
 		root->peer_copy = peer_copy;
+		root->direct_frame = (multi_flags & RT_HIP_MULTI_DIRECT_FRAME) != 0;
 		root->world = static_cast<uint32_t>(n_devices);
 		root->first_rank = 0;
 		for (int r = 1; r < n_devices; r++)
@@ -763,6 +765,11 @@ rt_hip_status scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene)
 }
 }
 
+namespace
+{
+	rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers);
+}
+
 extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 											  uint32_t width,
 											  uint32_t height,
@@ -772,6 +779,15 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 											  uint32_t* d_rgba8,
 											  float* d_rgb_f32,
 											  void* stream)
+{
+	return render_device(ctx, width, height, seed, flags, part, d_rgba8, d_rgb_f32, stream, false);
+}
+
+namespace
+{
+// whole_frame_buffers: d_rgba8 / d_rgb_f32 are the whole width x height frame and every pixel goes to its image row
+// (several GPUs rendering into one host frame); otherwise the rank's compact stripe buffer, as the public call documents
+rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers)
 {
 	if (!ctx || !d_rgba8)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: NULL argument");
@@ -802,6 +818,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	f.rank = p.rank;
 	f.world = p.world;
 	f.stripe_rows = p.stripe_rows;
+	f.frame_rows = whole_frame_buffers ? 1u : 0u;
 	f.stripe_shift = 0xFFFFFFFFu;
 	if ((p.stripe_rows & (p.stripe_rows - 1u)) == 0u)
 		for (f.stripe_shift = 0; (1u << f.stripe_shift) != p.stripe_rows; f.stripe_shift++)
@@ -858,6 +875,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 	ctx->stats.kernel_variant = variant;
 	ctx->stats.primary_samples = static_cast<uint64_t>(f.local_rows) * width * ((flags & RT_HIP_FLAG_PREVIEW) ? 1u : f.samples_per_pixel);
 	return ok();
+}
 }
 
 extern "C" rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
@@ -956,7 +974,7 @@ namespace
 		if (pin && !ctx->pinned_frame)
 		{
 			place_on_node(pixels, bytes, ctx->numa_node); // before the pages are locked where they are
-			if (hipHostRegister(pixels, bytes, hipHostRegisterMapped) == hipSuccess)
+			if (hipHostRegister(pixels, bytes, hipHostRegisterMapped | (ctx->direct_frame ? hipHostRegisterPortable : 0u)) == hipSuccess)
 			{
 				ctx->pinned_frame = pixels;
 				ctx->pinned_bytes = bytes;
@@ -990,6 +1008,54 @@ namespace
 		const size_t stripe_pixels = static_cast<size_t>(padded_rows) * width; // what every member sends
 		if (stripe_pixels * 3u > 0x7FFFFFFFull)
 			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: a %ux%u frame over %u ranks exceeds the gather's element count", width, height, world);
+
+		// RT_HIP_MULTI_DIRECT_FRAME: no gather at all.  The caller's back buffer is page-locked and mapped into every member's
+		// address space; each member's kernel stores its pixels straight into their image rows (system-scope stores over
+		// that GPU's own PCIe link), and the call is over when the last member's launch is.  Needs the page-locked buffer
+		// (RT_HIP_FLAG_PERSISTENT_FRAME) and all ranks in this process; the float mean still goes the gathered way.
+		if (root->direct_frame && have_root && n == static_cast<int>(world) && root->pinned_frame == pixels_rgba8888 && !rgb_f32)
+		{
+			bool mapped_everywhere = true;
+			std::vector<uint32_t*> views(static_cast<size_t>(n), nullptr);
+			for (int r = 0; r < n && mapped_everywhere; r++)
+			{
+				RT_HIP_TRY(hipSetDevice(member_of(root, r)->device));
+				void* view = nullptr;
+				if (hipHostGetDevicePointer(&view, pixels_rgba8888, 0) == hipSuccess && view)
+					views[static_cast<size_t>(r)] = static_cast<uint32_t*>(view);
+				else
+				{
+					(void)hipGetLastError();
+					mapped_everywhere = false;
+				}
+			}
+			if (mapped_everywhere)
+			{
+				for (int r = 0; r < n; r++)
+				{
+					rt_hip_ctx* member = member_of(root, r);
+					if (const rt_hip_status st = rt_hip_scene_upload(member, scene))
+						return st;
+					const rt_hip_partition part = { static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
+					if (const rt_hip_status st = render_device(member, width, height, seed, flags & render_flag_mask, &part, views[static_cast<size_t>(r)], nullptr, member->stream, true))
+						return st;
+				}
+				RT_HIP_TRY(hipSetDevice(root->device));
+				RT_HIP_TRY(hipEventSynchronize(root->render_end));
+				const auto t0 = std::chrono::steady_clock::now();
+				for (int r = 0; r < n; r++)
+				{
+					rt_hip_ctx* member = member_of(root, r);
+					RT_HIP_TRY(hipSetDevice(member->device));
+					RT_HIP_TRY(hipStreamSynchronize(member->stream));
+				}
+				RT_HIP_TRY(hipSetDevice(root->device));
+				root->stats.readback_ms = static_cast<float>(seconds_since(t0) * 1e3);
+				if (stats)
+					return rt_hip_stats_fetch(root, stats);
+				return ok();
+			}
+		}
 
 		// 1. every member: scene resident (re-uploaded only when the host columns changed), its share of the frame
 		//    launched on its own stream.  Nothing here waits for a GPU, so the members run concurrently.

@@ -237,12 +237,15 @@ namespace rt_hip
 			return ((local_row / p.stripe_rows) * p.world + p.rank) * p.stripe_rows + (local_row % p.stripe_rows);
 		}
 
+		// row of the output buffers that local row `ly` of this rank is written to (wave-uniform branch)
+		__device__ __forceinline__ uint32_t output_row(uint32_t ly, const frame_params& p) { return p.frame_rows ? global_row(ly, p) : ly; }
+
 		// :195-200 — mean, sqrt "gamma", pack, store
 		__device__ __forceinline__ void finish_pixel(vec3 colour, const frame_params& p, uint32_t lx, uint32_t ly, uint32_t* out_rgba, float* out_rgb)
 		{
 			const float n = static_cast<float>(p.samples_per_pixel);
 			const vec3 mean = { colour.x / n, colour.y / n, colour.z / n };
-			const size_t o = static_cast<size_t>(ly) * p.width + lx;
+			const size_t o = static_cast<size_t>(output_row(ly, p)) * p.width + lx;
 			if (out_rgb)
 			{
 				out_rgb[o * 3 + 0] = mean.x;
@@ -430,7 +433,7 @@ namespace rt_hip
 							sum = sum + sums[((c << q.pixels_log2) + pixel) * 3u + channel];
 					}
 					const float mean = sum / static_cast<float>(p.samples_per_pixel);
-					const size_t o = static_cast<size_t>(ly) * p.width + lx;
+					const size_t o = static_cast<size_t>(output_row(live ? ly : 0u, p)) * p.width + lx;
 					if (live && out_rgb)
 						out_rgb[o * 3u + channel] = mean;
 					const uint32_t byte = static_cast<uint32_t>(clamp01(__builtin_sqrtf(mean)) * 255.99999f);
@@ -963,7 +966,7 @@ namespace rt_hip
 			}
 			if (alive)
 			{
-				const size_t o = static_cast<size_t>(ly) * p.width + lx;
+				const size_t o = static_cast<size_t>(p.frame_rows ? gy : ly) * p.width + lx;
 				if (out_rgb)
 				{
 					out_rgb[o * 3 + 0] = colour.x;

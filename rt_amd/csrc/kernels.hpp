@@ -57,6 +57,8 @@ namespace rt_hip
 		uint32_t local_rows;			   // rows this rank renders (compact buffer height in use)
 		uint32_t rank, world, stripe_rows; // rt_hip_partition
 		uint32_t stripe_shift;			   // log2(stripe_rows) if that is a power of two, else 0xFFFFFFFF (general division)
+		uint32_t frame_rows;			   // != 0: the output buffers are the WHOLE frame, a pixel goes to its image row (several
+										   // GPUs storing straight into one host frame); 0: this rank's compact stripe buffer
 		uint32_t samples_per_pixel, max_bounces;
 		uint32_t frame_key_a, frame_key_b;  // the two halves of the mixed 64-bit seed (contract.hpp, random streams)
 		float sx, neg_sy;				   // 2/W and -(2/H): ndc = (fma(px, sx, -1), fma(py, neg_sy, 1))

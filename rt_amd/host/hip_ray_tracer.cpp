@@ -57,7 +57,10 @@ namespace
 				p = (*end == ',') ? end + 1 : end;
 			}
 		}
-		return rt_hip_create_multi(ctx, devices, n, RT_HIP_MULTI_NONE); // n == 0 fails there with a message
+		// RT_HIP_FRAME=direct: no gather — every GPU stores its pixels straight into the (page-locked) back buffer
+		const char* frame = std::getenv("RT_HIP_FRAME");
+		const uint32_t flags = (frame && std::strcmp(frame, "direct") == 0) ? static_cast<uint32_t>(RT_HIP_MULTI_DIRECT_FRAME) : static_cast<uint32_t>(RT_HIP_MULTI_NONE);
+		return rt_hip_create_multi(ctx, devices, n, flags); // n == 0 fails there with a message
 	}
 
 	// ModeFlags: 0 = mg_ray_tracer's scatter table; RT_HIP_FLAG_SM_MATERIALS = sm_ray_tracer's (dielectrics refract);

@@ -50,9 +50,10 @@ def device_count() -> int:
 class HipRayTracer:
     """`device`: one GPU (rt_hip_create).  `devices`: a list of GPUs behind ONE render() call (rt_hip_create_multi):
     scene replicated, row stripes dealt round-robin, one RCCL gather to devices[0], one copy to the host.
-    `peer_copy`: move the stripes with hipMemcpyPeerAsync instead of RCCL (allows a device to appear twice: tests)."""
+    `peer_copy`: move the stripes with hipMemcpyPeerAsync instead of RCCL (allows a device to appear twice: tests).
+    `direct_frame`: no gather — every member stores its pixels straight into the caller's page-locked back buffer."""
 
-    def __init__(self, device: int = 0, devices: list[int] | None = None, peer_copy: bool = False, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None):
+    def __init__(self, device: int = 0, devices: list[int] | None = None, peer_copy: bool = False, direct_frame: bool = False, rank: int | None = None, world: int | None = None, unique_id: bytes | None = None):
         """`rank`, `world`, `unique_id`: one rank of a renderer with one process per GPU (rt_hip_create_rank; collective).
         The id comes from `unique_id()` on one process and must reach every rank unchanged."""
         self._lib = capi.hip_lib()
@@ -71,7 +72,7 @@ class HipRayTracer:
             self.devices = [device]
         else:
             ordinals = (C.c_int * len(devices))(*devices)
-            check(self._lib.rt_hip_create_multi(C.byref(self._ctx), ordinals, len(devices), capi.RT_HIP_MULTI_PEER_COPY if peer_copy else 0))
+            check(self._lib.rt_hip_create_multi(C.byref(self._ctx), ordinals, len(devices), (capi.RT_HIP_MULTI_PEER_COPY if peer_copy else 0) | (capi.RT_HIP_MULTI_DIRECT_FRAME if direct_frame else 0)))
             self.device = devices[0]
             self.devices = list(devices)
 

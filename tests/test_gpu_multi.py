@@ -152,3 +152,32 @@ def test_a_world_of_one_rank_goes_through_ncclcomminitrank():
             assert stats["segments"] == want_stats["segments"]
     with pytest.raises(rt_amd.RtHipError, match="invalid rank"):
         rt_amd.HipRayTracer(device=0, rank=2, world=2, unique_id=uid)
+
+
+@pytest.mark.parametrize("members", [2, 4, 8])
+def test_direct_frame_members_store_straight_into_the_back_buffer(members):
+    """RT_HIP_MULTI_DIRECT_FRAME: no stripe buffers, no gather, no assemble, no copy — every member's kernel writes its
+    pixels to their image rows of the caller's page-locked buffer.  Same frame, bit for bit."""
+    width, height, spp, seed = 320, 203, 7, 21  # 203 rows: ragged last stripe
+    pod = _scene("basic", spp).describe(width, height)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed)
+    with rt_amd.HipRayTracer(devices=[0] * members, peer_copy=True, direct_frame=True) as tracer:
+        back = np.full((height, width), 0x01020304, dtype=np.uint32)
+        for frame_seed in (seed + 1, seed):
+            _, _, stats = tracer.render(pod, width, height, seed=frame_seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back)
+        assert np.array_equal(back, want_rgba), f"{(back != want_rgba).sum()} pixels differ"
+        assert stats["segments"] == want_stats["segments"]
+        assert sum(tracer.member_stats(r)["segments"] for r in range(members)) == want_stats["segments"]
+        # the preview through the same path
+        want_preview, _, _ = oracle.render(pod, width, height, want_rgb=False, preview=True)
+        tracer.render(pod, width, height, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME | capi.RT_HIP_FLAG_PREVIEW, out=back)
+        assert np.array_equal(back, want_preview)
+        # without the page-locked buffer, or with the float mean asked for, the call takes the gathered way
+        rgba, rgb, _ = tracer.render(pod, width, height, seed=seed, want_rgb=True)
+        assert np.array_equal(rgba, want_rgba) and np.array_equal(rgb.view(np.uint32), want_rgb.view(np.uint32))
+        # a big-scene kernel (rolling tiles) writing image rows
+        field = _scene("synthetic-1500", 2).describe(96, 54)
+        want_field, _, _ = oracle.render(field, 96, 54, seed=3, want_rgb=False)
+        small = np.zeros((54, 96), dtype=np.uint32)
+        tracer.render(field, 96, 54, seed=3, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=small)
+        assert np.array_equal(small, want_field)
