@@ -162,11 +162,11 @@ struct rt_hip_ctx
 	// staging for the drop-in rt_hip_render()
 	device_buffer frame_rgba, frame_rgb;
 	uint64_t scene_fingerprint = 0; // of the last uploaded host columns: rt has no scene version counter (src/main.cpp:233-311)
-	// the caller's frame buffer, page-locked while it keeps arriving at the same address (the reference allocates its
-	// back buffer once per window size, src/window.cpp:61-64): the read-back is then one DMA instead of a staged copy
+	// the caller's frame buffer, page-locked and mapped into the GPU's address space while it keeps arriving at the same
+	// address (the reference allocates its back buffer once per window size, src/window.cpp:61-64): the kernel renders
+	// straight into it (one GPU, direct-frame members), or the assembled frame arrives by one DMA (gathered)
 	void* pinned_frame = nullptr;
 	size_t pinned_bytes = 0;
-	bool store_to_host = true; // render straight into a page-locked back buffer (see rt_hip_render)
 
 	// KAT scratch
 	device_buffer kat_in, kat_out;
@@ -1195,7 +1195,7 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		// there is no read-back step at all.  Otherwise the frame is rendered into HBM and copied.
 		uint32_t* d_frame = nullptr;
 		bool mapped = false;
-		if (ctx->pinned_frame && ctx->store_to_host)
+		if (ctx->pinned_frame)
 		{
 			void* device_view = nullptr;
 			if (hipHostGetDevicePointer(&device_view, pixels_rgba8888, 0) == hipSuccess && device_view)

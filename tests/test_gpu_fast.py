@@ -60,7 +60,7 @@ def test_fast_frames_of_the_baseline_scenes_stay_within_the_stated_tolerance(tra
     assert r["rgba8_within_1"] >= 0.9997  # measured >= 0.99993
     assert r["segments"] <= 5e-6  # measured <= 7e-7: flips are rare and go both ways
     assert r["mean"] <= 1e-5  # the image as a whole does not move
-    assert r["speedup"] > 1.05  # it is there to be faster (measured 1.20 .. 1.30)
+    assert r["speedup"] > 1.03  # it is there to be faster (measured 1.20 .. 1.30)
 
 
 def test_fast_config1_size(tracer):
