@@ -32,6 +32,7 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's host driver only supports dmabuf IPC (RCCL across processes)
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
 HBM_PEAK_GBPS = 8000.0  # same guide, HBM3E spec
