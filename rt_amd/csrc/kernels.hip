@@ -741,10 +741,10 @@ namespace rt_hip
 						const float dn = dot(d, normal);
 						const float k = 2.0f * dn;
 						const vec3 reflected = { fma(-k, normal.x, d.x), fma(-k, normal.y, d.y), fma(-k, normal.z, d.z) };
-						const float len = __builtin_sqrtf(dot(d, d));
+						const float len = sqrt_rn(dot(d, d)); // (== __builtin_sqrtf, bit for bit: contract.hpp)
 						const bool inside = dn > 0.0f;
 						const vec3 outward = inside ? vec3{ -normal.x, -normal.y, -normal.z } : normal;
-						const float eta = inside ? refl : 1.0f / refl;
+						const float eta = inside ? refl : rcp_rn(refl);
 						const float cosine = inside ? (refl * dn) / len : (-dn) / len;
 						float reflect_prob = 1.0f;
 						vec3 refracted = { 0.0f, 0.0f, 0.0f };
@@ -752,7 +752,7 @@ namespace rt_hip
 						const float sin2_t = (eta * eta) * fma(-cos_i, cos_i, 1.0f);
 						if (!(sin2_t > 1.0f)) // refract() returned true
 						{
-							const float cos_t = __builtin_sqrtf(1.0f - sin2_t);
+							const float cos_t = sqrt_rn(1.0f - sin2_t);
 							const float kk = fma(eta, cos_i, -cos_t);
 							refracted = { fma(kk, outward.x, eta * d.x), fma(kk, outward.y, eta * d.y), fma(kk, outward.z, eta * d.z) };
 							float r0 = (1.0f - refl) / (1.0f + refl);
