@@ -90,8 +90,8 @@ def test_hip_rasterizer_plugin_draws_the_oracle_preview_boxes_included(tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices", ["0", "all"])
-def test_plugin_with_rt_hip_devices_renders_through_the_multi_gpu_context(tmp_path, devices):
+@pytest.mark.parametrize("devices,frame", [("0", None), ("all", None), ("all", "direct")])
+def test_plugin_with_rt_hip_devices_renders_through_the_multi_gpu_context(tmp_path, devices, frame):
     """RT_HIP_DEVICES makes the plug-in create ONE rt_hip_create_multi context (RCCL communicator, gather, assemble, one
     copy) behind the same blocking render() — on this box 'all' is one GPU, which still takes that whole path."""
     import os
@@ -101,7 +101,7 @@ def test_plugin_with_rt_hip_devices_renders_through_the_multi_gpu_context(tmp_pa
     from tests.conftest import unpack
 
     ppm = tmp_path / "frame.ppm"
-    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "100x61", "--spp", "4", "--seed", "3", "--frames", "2", "--out", str(ppm), env=dict(os.environ, RT_HIP_DEVICES=devices))
+    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "100x61", "--spp", "4", "--seed", "3", "--frames", "2", "--out", str(ppm), env=dict(os.environ, RT_HIP_DEVICES=devices, **({"RT_HIP_FRAME": frame} if frame else {})))
     assert out.returncode == 0, out.stderr
     assert "error:" not in out.stderr
     header = b"P6\n100 61\n255\n"
