@@ -181,3 +181,28 @@ def test_direct_frame_members_store_straight_into_the_back_buffer(members):
         small = np.zeros((54, 96), dtype=np.uint32)
         tracer.render(field, 96, 54, seed=3, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=small)
         assert np.array_equal(small, want_field)
+
+
+MULTI_RANDOM_CASES = int(__import__("os").environ.get("RT_HIP_RANDOM_CASES", "6"))
+
+
+@pytest.mark.parametrize("case", range(MULTI_RANDOM_CASES))
+def test_random_scenes_through_gathered_and_direct_members(case):
+    """Random scenes, sizes, sample counts and member counts through both multi-GPU forms (gathered over peer copies, and
+    direct into the page-locked buffer), each frame equal to the oracle's."""
+    from tests.test_gpu_parity import random_scene
+
+    rng = np.random.default_rng(5000 + case)
+    spheres, planes, materials, camera = random_scene(rng)
+    width, height = int(rng.integers(17, 200)), int(rng.integers(9, 120))
+    spp, bounces, members = int(rng.integers(1, 24)), int(rng.integers(1, 10)), int(rng.integers(2, 9))
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
+    seed = int(rng.integers(0, 2**63))
+    want, _, want_stats = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    for direct in (False, True):
+        with rt_amd.HipRayTracer(devices=[0] * members, peer_copy=True, direct_frame=direct) as tracer:
+            back = np.zeros((height, width), dtype=np.uint32)
+            _, _, stats = tracer.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back)
+            assert np.array_equal(back, want), f"case {case}, {members} members, direct={direct}: {(back != want).sum()} pixels differ"
+            assert stats["segments"] == want_stats["segments"]
