@@ -27,7 +27,7 @@ $(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
 	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl -lpthread
 
 $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
@@ -39,7 +39,7 @@ variant:
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
 	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
 	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl -lpthread
 
 # windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
 HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp

@@ -12,8 +12,20 @@ scenes/basic.toml (BASELINE.json `metric`), on N MI355X of one node.
 A "step" is one whole `render(scene, back_buffer)` as the reference makes it: host scene
 columns in, finished frame in the caller's HOST buffer out, ONE frame at a time — scene fingerprint check (the columns
 were uploaded during warm-up and are not re-sent while unchanged), kernel(s), for N > 1 the RCCL gather to rank 0 and the
-de-interleave, and the device-to-host transfer of the frame.  `value` is that drop-in rate; the kernel-only rate (scene
+de-interleave, and the transfer of the frame to the host.  `value` is that drop-in rate; the kernel-only rate (scene
 resident, frame left in HBM) is carried beside it as `kernel_only`.  The frame is fixed as N grows: scaling is STRONG.
+
+N > 1 under torchrun runs the step in TWO forms, one after the other, and says so in the line:
+  * `torch`   — torch.distributed.gather + rt_hip_assemble_device + a copy to a pinned host frame: building blocks that
+                every ROCm installation exercises;
+  * `library` — every process is one rank of the module's OWN renderer (rt_hip_create + rt_hip_join_ranks:
+                ncclCommInitRank; one ncclGather inside librt_hip.so; the root assembles straight into the page-locked
+                back buffer): the product path, and what `value` reports when it came up, produced the very frame the
+                `torch` form produced, and finished; otherwise `value` is the `torch` form's and `paths.library` says why.
+The ranks vote before anything collective is entered, the collective join has a deadline, and a watchdog turns a hang
+of the library form into the `torch` line instead of a lost run.  Every N > 1 line carries what RCCL reports about the
+communicator (`rccl`), every rank's own kernel time (`per_rank`) and the root's render / gather / assemble / copy split
+(`drop_in_breakdown`).
 
 The `roofline` object prices the render kernel against the FP32 vector-ALU peak — the bound SURVEY.md §8d identifies for
 this path (a 3-sphere scene is ~100 bytes; the only compulsory HBM traffic is the 4 B/pixel frame) — from the kernel's
@@ -27,6 +39,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 from pathlib import Path
 
@@ -80,6 +93,23 @@ def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float
     }
 
 
+PHASE_KEYS = ("render_ms", "gather_ms", "assemble_ms", "copy_ms", "host_issue_ms", "host_wait_ms")
+
+
+def mean_phases(samples: list[dict]) -> dict:
+    """Average of rt_hip_phases over the timed steps (root's stream events and host clocks)."""
+    if not samples:
+        return {}
+    out = {k: round(sum(s[k] for s in samples) / len(samples), 4) for k in PHASE_KEYS}
+    out["transport"] = samples[-1]["transport"]
+    out["scene_resident"] = int(all(s["scene_resident"] for s in samples))
+    return out
+
+
+def spread(values: list[float]) -> dict:
+    return {"kernel_ms": [round(v, 4) for v in values], "kernel_ms_min": round(min(values), 4), "kernel_ms_max": round(max(values), 4)}
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,11 +125,12 @@ def main() -> None:
     ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
     ap.add_argument("--fast", action="store_true", help="RT_HIP_FLAG_FAST: the tolerance-bound arithmetic (raw v_rsq/v_rcp), a second bench line; never the parity contract")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
+    ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode with --gather torch only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
-    ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` side leg (profiling runs: every render launch of the process is then a step of the drop-in loop)")
-    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` = every process creates one rank of the module's own renderer (rt_hip_create_rank: ncclCommInitRank, the gather inside librt_hip.so, torch.distributed only hands out the id and keeps time); `torch` = torch.distributed.gather + rt_hip_assemble_device.  `library` falls back to `torch` if the communicator cannot be created (and always with --backend gloo)")
+    ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` and `plug_in_call` side legs (profiling runs: every render launch of the process is then a step of the drop-in loop)")
+    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` (default) = the torch form first, then the module's own renderer (see the docstring), `value` from the latter when it validated; `torch` = the torch form only")
+    ap.add_argument("--library-deadline-s", type=float, default=0.0, help="watchdog of the library form under torchrun: seconds it may take in all before the torch form's line is printed instead (0 = 120 s + 50 x what the torch form took)")
     ap.add_argument("--direct-frame", action="store_true", help="single-process N > 1 only: RT_HIP_MULTI_DIRECT_FRAME — no gather, every GPU stores its pixels straight into the page-locked back buffer")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
@@ -127,6 +158,7 @@ def main() -> None:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group("gloo")
+    vote_device = "cuda" if args.backend == "nccl" else "cpu"
 
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
     pod = scene.describe(args.width, args.height)
@@ -141,136 +173,17 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    kernel_ms_sum = 0.0
-    readback_ms_sum = 0.0
-    kernel_only = None
-    if single_process:
-        # ---- ONE process: rt_hip_render, the drop-in call, on one context (1 GPU) or one multi-GPU context ----
-        if n_gpus == 1:
-            tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
-            transport = None
-        elif args.same_device:
-            tracer = rt_amd.HipRayTracer(devices=[device] * n_gpus, peer_copy=True, direct_frame=args.direct_frame)
-            transport = "peer copies on one device (rehearsal)"
-        else:
-            tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)), direct_frame=args.direct_frame)
-            transport = "RCCL: ncclCommInitAll + one ncclGather to device 0"
-        if n_gpus > 1 and args.direct_frame:
-            transport = "NO gather (RT_HIP_MULTI_DIRECT_FRAME): every GPU stores its pixels straight into the mapped back buffer"
-        back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
-        render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+    def settle(render_once):
+        until = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < until:  # untimed: brings the clocks up from idle; the W warm-up steps follow
+            render_once()
 
-        def step():
-            return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
-
-        t_first = time.perf_counter()
-        step()  # the very first call: scene upload, page-locking and placing the back buffer, cold clocks (reported, not timed)
-        first_call_ms = (time.perf_counter() - t_first) * 1e3
-        settle_until = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < settle_until:  # untimed: brings the clocks up from idle; the W warm-up steps follow
-            step()
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            stats = step()  # blocking: returns with the frame in back_buffer
-            # HIP events on the launch stream around this step's kernel (several GPUs: member 0's launch, its share of the frame)
-            kernel_ms_sum += stats["render_ms"] if n_gpus == 1 else tracer.member_stats(0)["render_ms"]
-            readback_ms_sum += stats["readback_ms"]
-        fence()
-        elapsed = time.perf_counter() - t0
-        member0 = tracer.member_stats(0) if n_gpus > 1 else stats
-
-        if n_gpus == 1 and not args.no_kernel_only:
-            # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
-            frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
-            stream = torch.cuda.current_stream().cuda_stream
-            for _ in range(2):
-                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
-            torch.cuda.synchronize()
-            per_frame = (time.perf_counter() - t1) / args.steps
-            kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
-    else:
-        # ---- one process per GPU (torchrun): stripes -> ONE gather over RCCL -> assemble -> host frame on rank 0 ----
-        in_flight = max(1, args.frames_in_flight)
-        rank_tracer = None
-        if args.gather == "library" and args.backend == "nccl" and in_flight == 1:
-            # every process = one rank of the module's own multi-GPU renderer; torch.distributed only carries the 128-byte id
-            ids = [rt_amd.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            try:
-                rank_tracer = rt_amd.HipRayTracer(device=device, rank=rank, world=world, unique_id=ids[0])
-            except rt_amd.RtHipError as e:
-                print(f"rank {rank}: rt_hip_create_rank failed ({e}); falling back to torch.distributed.gather", file=sys.stderr)
-            created = torch.tensor([1 if rank_tracer is not None else 0], device="cuda")
-            dist.all_reduce(created, op=dist.ReduceOp.MIN)
-            if int(created.item()) == 0 and rank_tracer is not None:
-                rank_tracer.close()
-                rank_tracer = None
-        if rank_tracer is not None:
-            tracers = [rank_tracer]
-            tracer = rank_tracer
-            tracer.upload(pod)
-            transport = "inside librt_hip.so: ncclCommInitRank + one ncclGather to rank 0 (torch.distributed only hands out the id)"
-            back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
-            render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
-            padded = rt_amd.padded_local_rows(args.height, world)
-
-            def step():  # collective and blocking: rank 0 returns with the frame in its back buffer
-                tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)
-                return tracer
-        else:
-            tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
-            tracer = tracers[0]
-            for t in tracers:
-                t.upload(pod)
-            frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
-            padded = frame_maker.padded_rows
-            host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
-            transport = "torch.distributed gather (backend nccl = RCCL)" if args.backend == "nccl" else "gloo rehearsal"
-
-            def step():
-                frame = frame_maker.render(seed=args.seed, flags=flags)
-                if frame is not None:
-                    host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
-                if in_flight == 1:
-                    torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
-                return tracers[(frame_maker.frames - 1) % in_flight]
-
-        settle_until = time.perf_counter() + args.settle_ms * 1e-3
-        scratch = torch.empty((padded, args.width), dtype=torch.int32, device=f"cuda:{device}")
-        while time.perf_counter() < settle_until:  # untimed, rank-local (no collective): this rank's own share, over and over
-            tracer.render_device(args.width, args.height, scratch.data_ptr(), seed=args.seed, flags=flags, partition=(rank, world, capi.RT_HIP_DEFAULT_STRIPE_ROWS), stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            used = step()
-            if in_flight == 1:
-                kernel_ms_sum += used.stats()["render_ms"]
-        fence()
-        elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        member0 = tracers[(args.steps - 1) % in_flight].stats()
-        stats = member0
-        if in_flight > 1:
-            kernel_ms_sum = float("nan")
-
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = samples_total * args.steps / elapsed / 1e6
-        kernel_ms = kernel_ms_sum / args.steps
+    def build_line(form, elapsed_s, kernels_ms, member, transport_text, more):
+        ms_per_step = elapsed_s / args.steps * 1e3
+        value = samples_total * args.steps / elapsed_s / 1e6
+        kernel_ms = kernels_ms[0]
         # roofline of the dominant kernel: rank/member 0's launch (its share of the frame), algorithmic flops over its duration
-        flops = algorithmic_flops(member0["primary_samples"], member0["segments"], pod.n_spheres, pod.n_planes)
+        flops = algorithmic_flops(member["primary_samples"], member["segments"], pod.n_spheres, pod.n_planes)
         duration_ms = kernel_ms if kernel_ms == kernel_ms else ms_per_step  # NaN (two frames in flight): wall per frame
         achieved_tflops = flops / (duration_ms * 1e-3) / 1e12
         local_rows = rt_amd.local_rows(args.height, 0, n_gpus)
@@ -287,7 +200,7 @@ def main() -> None:
                 traffic = None
         roofline = {
             "bound": "valu_fp32",
-            "kernel": f"render_{member0['kernel']}",
+            "kernel": f"render_{member['kernel']}",
             "achieved": round(achieved_tflops, 3),
             "peak": FP32_VALU_PEAK_TFLOPS,
             "unit": "TFLOP/s",
@@ -296,7 +209,7 @@ def main() -> None:
             "kernel_ms": round(duration_ms, 4),
             "kernel_ms_source": "HIP events on the launch stream around every launch of the timed region (rt_hip_stats.render_ms), averaged" if kernel_ms == kernel_ms else "wall per frame (two frames in flight)",
             "algorithmic_flops_per_launch": flops,
-            "mean_segments_per_sample": round(member0["segments"] / max(member0["primary_samples"], 1), 4),
+            "mean_segments_per_sample": round(member["segments"] / max(member["primary_samples"], 1), 4),
             "hbm": {
                 "algorithmic_bytes_per_launch": hbm_bytes,
                 "achieved_GBps": round(hbm_bytes / (duration_ms * 1e-3) / 1e9, 3),
@@ -305,12 +218,6 @@ def main() -> None:
             },
         }
         synthetic = args.scene.startswith("synthetic")
-        if n_gpus == 1 and single_process:
-            parallelism = "1 GPU"
-        elif single_process:
-            parallelism = f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, {transport}, device assemble, one D2H"
-        else:
-            parallelism = f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {transport} to rank 0, device assemble, D2H on rank 0"
         line = {
             "metric": f"Mrays/s (W*H*spp per second) and wall-clock, {args.width}x{args.height}x{args.spp}spp scenes/{args.scene}.toml",
             "value": round(value, 1),
@@ -329,16 +236,236 @@ def main() -> None:
                 "step": "one blocking render(): host scene in (columns fingerprinted, resident in HBM since warm-up), finished frame in the caller's host buffer out, one frame at a time",
                 "spheres": pod.n_spheres,
                 "planes": pod.n_planes,
-                "kernel": member0["kernel"],
-                "arithmetic": "contract v2-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v2 (bit-exact against the oracle)",
-                "parallelism": parallelism,
-                "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight),
+                "kernel": member["kernel"],
+                "arithmetic": "contract v3-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v3 (bit-exact against the oracle)",
+                "parallelism": transport_text,
+                "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight if args.gather == "torch" else 1),
                 "clock_settle_ms": args.settle_ms,
             },
             "roofline": roofline,
         }
+        line.update(more)
+        return line
+
+    extras: dict = {}
+    kernel_only = None
+    plug_in_call = None
+    if single_process:
+        # ---- ONE process: rt_hip_render, the drop-in call, on one context (1 GPU) or one multi-GPU context ----
+        if n_gpus == 1:
+            tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
+        elif args.same_device:
+            tracer = rt_amd.HipRayTracer(devices=[device] * n_gpus, peer_copy=True, direct_frame=args.direct_frame)
+        else:
+            tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)), direct_frame=args.direct_frame)
+        back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
+        render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+
+        def step():
+            return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
+
+        t_first = time.perf_counter()
+        step()  # the very first call: scene upload, page-locking and placing the back buffer, cold clocks (reported, not timed)
+        first_call_ms = (time.perf_counter() - t_first) * 1e3
+        settle(step)
+        for _ in range(args.warmup):
+            step()
+        fence()
+        member_kernel_ms = [0.0] * n_gpus
+        phase_samples = []
+        readback_ms_sum = 0.0
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stats = step()  # blocking: returns with the frame in back_buffer
+            # HIP events on each member's launch stream around this step's kernel (its share of the frame)
+            if n_gpus == 1:
+                member_kernel_ms[0] += stats["render_ms"]
+            else:
+                for r in range(n_gpus):
+                    member_kernel_ms[r] += tracer.member_stats(r)["render_ms"]
+            readback_ms_sum += stats["readback_ms"]
+            phase_samples.append(tracer.phases())
+        fence()
+        elapsed = time.perf_counter() - t0
+        member0 = tracer.member_stats(0) if n_gpus > 1 else stats
+        per_rank_kernel_ms = [v / args.steps for v in member_kernel_ms]
+        phases = mean_phases(phase_samples)
+        transport = phases.get("transport", "none")
+        extras["drop_in_breakdown"] = dict(
+            {"kernel_ms": round(per_rank_kernel_ms[0], 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(elapsed / args.steps * 1e3, 4), "first_call_ms": round(first_call_ms, 3)},
+            **{k: phases[k] for k in PHASE_KEYS if k in phases},
+        )
+        if n_gpus > 1:
+            infos = [tracer.comm_info(r) for r in range(n_gpus)]
+            extras["rccl"] = {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_member": [i["rank"] for i in infos], "transport": transport, "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice per member" if transport == "rccl_gather" else "no communicator (this transport does not use RCCL)"}
+            extras["per_rank"] = spread(per_rank_kernel_ms)
+
+        if n_gpus == 1 and not args.no_kernel_only:
+            # side figure: the call as the plug-in makes it (stats == NULL: nothing but the launch and the wait is enqueued)
+            for _ in range(2):
+                tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer, stats=False)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer, stats=False)
+            per_frame = (time.perf_counter() - t1) / args.steps
+            plug_in_call = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "rt_hip_render with stats == NULL, as shim/hip_ray_tracer.cpp calls it: no timing events, no counter traffic (the timed steps above keep them, for the roofline's kernel time)"}
+            # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
+            frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
+            stream = torch.cuda.current_stream().cuda_stream
+            for _ in range(2):
+                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tracer.render_device(args.width, args.height, frame.data_ptr(), seed=args.seed, flags=flags, stream=stream)
+            torch.cuda.synchronize()
+            per_frame = (time.perf_counter() - t1) / args.steps
+            kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
+        tracers = [tracer]
+        parallelism = "1 GPU" if n_gpus == 1 else f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, transport {transport}"
+    else:
+        # ---- one process per GPU (torchrun) ----
+        in_flight = max(1, args.frames_in_flight) if args.gather == "torch" else 1
+        padded = rt_amd.padded_local_rows(args.height, world)
+        tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
+        for t in tracers:
+            t.upload(pod)
+        scratch = torch.empty((padded, args.width), dtype=torch.int32, device=f"cuda:{device}")
+
+        def own_share():  # rank-local (no collective): this rank's own share, for the clocks
+            tracers[0].render_device(args.width, args.height, scratch.data_ptr(), seed=args.seed, flags=flags, partition=(rank, world, capi.RT_HIP_DEFAULT_STRIPE_ROWS), stream=torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+
+        def timed(step_fn, kernel_ms_of):
+            """W warm-up steps, then exactly K steps between two fences; max over ranks; every rank's mean kernel time."""
+            for _ in range(args.warmup):
+                step_fn()
+            fence()
+            kernel_sum = 0.0
+            t_begin = time.perf_counter()
+            for _ in range(args.steps):
+                used = step_fn()
+                kernel_sum += kernel_ms_of(used)
+            fence()
+            local = time.perf_counter() - t_begin
+            t = torch.tensor([local], dtype=torch.float64, device=vote_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            kernels = [None] * world
+            dist.all_gather_object(kernels, kernel_sum / args.steps)
+            return float(t.item()), [float(k) for k in kernels]
+
+        # -- form 1: torch.distributed.gather + rt_hip_assemble_device + copy to a pinned host frame --
+        frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
+        host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
+
+        def torch_step():
+            frame = frame_maker.render(seed=args.seed, flags=flags)
+            if frame is not None:
+                host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
+            if in_flight == 1:
+                torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
+            return tracers[(frame_maker.frames - 1) % in_flight]
+
+        settle(own_share)
+        t_form = time.perf_counter()
+        torch_elapsed, torch_kernels = timed(torch_step, (lambda used: used.stats()["render_ms"]) if in_flight == 1 else (lambda used: float("nan")))
+        torch.cuda.synchronize()
+        torch_form_seconds = time.perf_counter() - t_form
+        torch_member0 = tracers[(args.steps - 1) % in_flight].stats()
+        torch_transport = "torch.distributed.gather (backend nccl = RCCL)" if args.backend == "nccl" else "torch.distributed.gather over gloo (rehearsal: stripes staged through host memory)"
+        paths = {"torch": {"ms_per_step": round(torch_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / torch_elapsed / 1e6, 1), "transport": torch_transport, "per_rank": spread(torch_kernels) if in_flight == 1 else None}}
+        chosen = "torch"
+        elapsed, per_rank_kernel_ms, member0, transport = torch_elapsed, torch_kernels, torch_member0, torch_transport
+        stats = torch_member0
+
+        # -- form 2: the module's own renderer, one rank per process --
+        if args.gather == "library" and args.backend == "nccl":
+            deadline = args.library_deadline_s or (120.0 + 50.0 * torch_form_seconds)
+            finished = threading.Event()
+            torch_line_ready = {}
+
+            def watchdog():
+                if finished.wait(deadline):
+                    return
+                # the library form hung (a collective that never completes cannot be cancelled): the run still reports
+                if rank == 0 and torch_line_ready:
+                    line = torch_line_ready["make"](f"hung: no result within {deadline:.0f} s; the processes were ended by the benchmark's watchdog")
+                    print(json.dumps(line), flush=True)
+                sys.stdout.flush()
+                os._exit(0)
+
+            def make_torch_line(why):
+                paths["library"] = {"status": why}
+                more = {"paths": paths, "value_from": "torch", "per_rank": spread(torch_kernels), "rccl": {"ranks": world, "devices": None, "transport": torch_transport, "source": "torch.distributed's process group (the module's own communicator did not finish)"}}
+                return build_line("torch", torch_elapsed, torch_kernels, torch_member0, f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {torch_transport}", more)
+
+            library = {"status": "not attempted"}
+            rank_tracer, reason = distributed.negotiate_rank_renderer(
+                create=lambda: rt_amd.HipRayTracer(device=device),
+                join=lambda t, unique: t.join_ranks(rank, world, unique, timeout_ms=int(min(deadline, 120.0) * 1e3)),
+                make_id=rt_amd.unique_id,
+                vote_device=vote_device,
+                log=lambda message: print(message, file=sys.stderr, flush=True),
+            )
+            if rank_tracer is None:
+                library = {"status": f"not available: {reason}"}
+            else:
+                tracers.append(rank_tracer)
+                back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
+                render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+                phase_samples: list[dict] = []
+
+                def library_step():  # collective and blocking: rank 0 returns with the frame in its back buffer
+                    if os.environ.get("RT_BENCH_TEST_HANG"):  # tests/test_bench_contract.py: the watchdog's rehearsal
+                        time.sleep(3600)
+                    return rank_tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
+
+                torch_line_ready["make"] = make_torch_line
+                threading.Thread(target=watchdog, daemon=True).start()
+                # validation: the very frame the torch form delivered
+                library_step()
+                same = True
+                if rank == 0:
+                    same = bool(np.array_equal(back_buffer.view(np.int32), host_frame.numpy()))
+                if not distributed.all_agree(same, vote_device):
+                    library = {"status": "frame differs from the torch form's frame: not used"}
+                else:
+
+                    def measured_step():
+                        s = library_step()
+                        phase_samples.append(rank_tracer.phases())
+                        return s
+
+                    lib_elapsed, lib_kernels = timed(measured_step, lambda s: s["render_ms"])
+                    phase_samples[:] = phase_samples[-args.steps :]
+                    infos = [None] * world
+                    dist.all_gather_object(infos, rank_tracer.comm_info())
+                    library = {"status": "ok", "ms_per_step": round(lib_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / lib_elapsed / 1e6, 1), "per_rank": spread(lib_kernels)}
+                    chosen = "library"
+                    elapsed, per_rank_kernel_ms, member0 = lib_elapsed, lib_kernels, rank_tracer.stats()
+                    stats = member0
+                    transport = "inside librt_hip.so: rt_hip_create + rt_hip_join_ranks (ncclCommInitRank) + one ncclGather to rank 0; torch.distributed only hands out the id, votes and keeps time"
+                    phases = mean_phases(phase_samples)
+                    extras["drop_in_breakdown"] = dict({"kernel_ms": round(lib_kernels[0], 4), "wall_ms": round(lib_elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases})
+                    extras["rccl"] = {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on every rank's communicator"}
+                finished.set()
+            paths["library"] = library
+        elif args.gather == "library":
+            paths["library"] = {"status": "not attempted: --backend gloo rehearses the torch form only"}
+        extras["paths"] = paths
+        extras["value_from"] = chosen
+        extras["per_rank"] = spread(per_rank_kernel_ms) if in_flight == 1 else None
+        if "rccl" not in extras and args.backend == "nccl":
+            extras["rccl"] = {"ranks": world, "devices": None, "transport": transport, "source": "torch.distributed's process group (the module's own communicator was not used)"}
+        parallelism = f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {transport}"
+
+    if rank == 0:
         if single_process:
-            line["drop_in_breakdown"] = {"kernel_ms": round(kernel_ms, 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(ms_per_step, 4), "first_call_ms": round(first_call_ms, 3)}
+            line = build_line("single", elapsed, per_rank_kernel_ms, member0, parallelism, extras)
+        else:
+            line = build_line(extras["value_from"], elapsed, per_rank_kernel_ms, member0, parallelism, extras)
+        if plug_in_call:
+            line["plug_in_call"] = plug_in_call
         if kernel_only:
             line["kernel_only"] = kernel_only
         if n_gpus == 1 and single_process and args.cpu_baseline_seconds > 0:
@@ -348,10 +475,8 @@ def main() -> None:
     if not single_process:
         dist.barrier()
         dist.destroy_process_group()
-        for t in tracers:
-            t.close()
-    else:
-        tracer.close()
+    for t in tracers:
+        t.close()
 
 
 if __name__ == "__main__":

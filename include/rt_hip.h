@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 3u
+#define RT_HIP_ABI_VERSION 4u
 
 typedef enum rt_hip_status
 {
@@ -34,7 +34,8 @@ typedef enum rt_hip_status
 	RT_HIP_NO_DEVICE		 = 2, /* no gfx950 device visible / bad device ordinal */
 	RT_HIP_RUNTIME_ERROR	 = 3, /* a HIP call failed; message carries hipGetErrorString */
 	RT_HIP_NO_SCENE			 = 4, /* render requested before a scene was uploaded */
-	RT_HIP_UNSUPPORTED		 = 5  /* unknown flag bits */
+	RT_HIP_UNSUPPORTED		 = 5, /* unknown flag bits */
+	RT_HIP_TIMEOUT			 = 6  /* rt_hip_join_ranks: the other ranks did not arrive within the deadline */
 } rt_hip_status;
 
 /* Material kinds, in the order of `enum class material_type` (reference src/common.hpp:105-115).
@@ -189,7 +190,13 @@ enum
 	 * per-pixel float mean agrees to a few 1e-6 relative wherever no sample's hit/miss decision flipped at a silhouette
 	 * (tests/test_gpu_fast.py states and checks the bounds).  Not available with RT_HIP_FLAG_SM_MATERIALS or
 	 * RT_HIP_FLAG_PREVIEW.  Opt-in; flags == 0 stays the parity contract. */
-	RT_HIP_FLAG_FAST = 1u << 6
+	RT_HIP_FLAG_FAST = 1u << 6,
+	/* rt_hip_render only: keep the work counters and the kernel's device time of this frame for a later
+	 * rt_hip_stats_fetch / rt_hip_phases_fetch even though `stats` is NULL.  A call with stats == NULL and without this flag
+	 * is the plug-in's call (shim/hip_ray_tracer.cpp): nothing but the launch and the wait is enqueued — no timing events, no
+	 * zeroing and read-back of the counters — which is what the launch-bound low-resolution preview frames of
+	 * reference src/main.cpp:315-321 want; rt_hip_stats_fetch after such a frame reports render_ms = 0 and segments = 0. */
+	RT_HIP_FLAG_STATS = 1u << 7
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;
@@ -257,6 +264,32 @@ rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int 
 #define RT_HIP_UNIQUE_ID_BYTES 128
 rt_hip_status rt_hip_unique_id(char out_id[RT_HIP_UNIQUE_ID_BYTES]);
 rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES]);
+/*
+ * rt_hip_create_rank in two halves, so that the part that can fail on ONE rank alone — no such device, not a gfx950, out
+ * of memory — is over before anything collective starts (a rank that fails inside rt_hip_create_rank leaves the others
+ * waiting in ncclCommInitRank):
+ *   1. every process: rt_hip_create(&ctx, device)                                — local, may fail alone
+ *   2. the launcher lets the ranks agree that all of them hold a context (bench.py: one all_reduce), and only then
+ *   3. every process: rt_hip_join_ranks(ctx, rank, world, id, timeout_ms)        — collective (rccl.h: ncclCommInitRank)
+ * rt_hip_join_ranks waits at most `timeout_ms` milliseconds for the communicator (0 = RT_HIP_JOIN_TIMEOUT_MS from the
+ * environment, else 120 000) and then gives up with RT_HIP_TIMEOUT; the context stays a valid single-GPU context, which the
+ * caller may use or destroy.  On success the context is what rt_hip_create_rank returns.
+ */
+rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES], uint32_t timeout_ms);
+
+/* How the stripes of a multi-GPU frame reach the root: what a context was created with (and what a bench line should say). */
+enum
+{
+	RT_HIP_TRANSPORT_NONE		  = 0, /* one GPU: nothing to exchange */
+	RT_HIP_TRANSPORT_RCCL_GATHER  = 1, /* one ncclGather to rank 0 */
+	RT_HIP_TRANSPORT_PEER_COPY	  = 2, /* RT_HIP_MULTI_PEER_COPY: hipMemcpyPeerAsync into the root */
+	RT_HIP_TRANSPORT_DIRECT_FRAME = 3  /* RT_HIP_MULTI_DIRECT_FRAME took effect in the most recent frame: no exchange at all */
+};
+/* What member `member` of the context talks through, as RCCL itself reports it (rccl.h: ncclCommCount, ncclCommUserRank,
+ * ncclCommCuDevice): the communicator's size, this member's rank in it, and the device the communicator lives on.  Contexts
+ * without a communicator (one GPU, peer copies) report the context's own world / rank / device.  Any out pointer may be NULL. */
+rt_hip_status rt_hip_comm_info(const rt_hip_ctx* ctx, int member, int* out_ranks, int* out_rank, int* out_device, uint32_t* out_transport);
+
 /* number of members of a context (1 for rt_hip_create) and the device of member `rank` */
 rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count);
 rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device);
@@ -270,6 +303,15 @@ rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_s
 rt_hip_status rt_hip_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
 /* max over ranks of rt_hip_local_rows: the per-rank buffer height used for the equal-sized gather. */
 rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
+
+/*
+ * What rt_hip_render does with the caller's columns before anything touches a GPU, on its own (pure host code; usable
+ * without a device): the pointer / count check, the material-index check (the reference's loader refuses out-of-range
+ * indices, src/scene.cpp:568-574) and the fingerprint that decides whether the columns resident in HBM are still the
+ * caller's (rt has no scene version counter, src/main.cpp:233-311).  Reads exactly n_* rows of every column — never the
+ * padding rows soagen keeps behind size() (vendor/soagen.hpp:3777,7075-7082).  out_fingerprint may be NULL.
+ */
+rt_hip_status rt_hip_scene_check(const rt_hip_scene* scene, uint64_t* out_fingerprint);
 
 /* ---- the hot path ----------------------------------------------------------------------------------------------- */
 
@@ -313,6 +355,24 @@ rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
 rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats);
 
 /*
+ * Where the time of the most recent rt_hip_render went (frames rendered with `stats` or RT_HIP_FLAG_STATS; otherwise the
+ * device times are 0).  Device times come from HIP events on the root's stream; on one GPU only render_ms is non-zero.
+ * Nothing in the reference corresponds: it prints no timing at all (src/main.cpp:30-47).
+ */
+typedef struct rt_hip_phases
+{
+	float render_ms;	 /* the root member's kernel (its share of the frame) */
+	float gather_ms;	 /* end of the root's kernel -> every rank's stripes are on the root (waits for the slowest rank) */
+	float assemble_ms;	 /* de-interleave; with a page-locked back buffer this IS the transfer to the host (stores over PCIe) */
+	float copy_ms;		 /* device-to-host copy of the assembled frame (0 when it was assembled straight into the back buffer) */
+	float host_issue_ms; /* host wall time from entry into rt_hip_render until everything was enqueued */
+	float host_wait_ms;	 /* host wall time blocked until the frame was complete */
+	uint32_t transport;	 /* RT_HIP_TRANSPORT_* that this frame took */
+	uint32_t scene_resident; /* 1: the columns' fingerprint matched, nothing was uploaded */
+} rt_hip_phases;
+rt_hip_status rt_hip_phases_fetch(rt_hip_ctx* ctx, rt_hip_phases* out_phases);
+
+/*
  * The drop-in for renderer_interface::render(const scene&, image_view&, muu::thread_pool&)
  * (src/renderer.hpp:11; mg_ray_tracer.cpp:178): upload `scene`, render the whole frame on the context's
  * GPU, and copy it into the caller's HOST pixel buffer (image_view::data(), width*height uint32) before
@@ -353,7 +413,8 @@ rt_hip_status rt_hip_kat_closest_hit(rt_hip_ctx* ctx,
 rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
 
 /* Runs ALL 2^32 binary32 bit patterns through the kernels' shortened sqrt / reciprocal / reciprocal-sqrt sequences and
- * compares each result, bit for bit, with the compiler's general correctly rounded expansion.
+ * compares each result, bit for bit, with the compiler's general correctly rounded expansion (sqrt, reciprocal) and with
+ * the arithmetic contract's definition of normalize()'s reciprocal square root evaluated through binary64.
  * out_mismatches[k] = number of differing inputs, out_first[k] = smallest differing input's bits (valid if count > 0),
  * k = 0 sqrt, 1 reciprocal, 2 reciprocal of sqrt.  All three counts must be 0. */
 rt_hip_status rt_hip_kat_exhaustive_math(rt_hip_ctx* ctx, uint64_t out_mismatches[3], uint32_t out_first[3]);

@@ -60,6 +60,10 @@ def lib() -> C.CDLL:
         l.oracle_closest_hit.argtypes = [C.POINTER(RtHipScene), C.c_uint32] + [C.c_void_p] * 6
         l.oracle_sqrt_div.restype = None
         l.oracle_sqrt_div.argtypes = [C.c_uint32] + [C.c_void_p] * 4
+        l.oracle_inv_sqrt.restype = None
+        l.oracle_inv_sqrt.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+        l.oracle_inv_sqrt_step.restype = None
+        l.oracle_inv_sqrt_step.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         l.oracle_pack.restype = C.c_uint32
         l.oracle_pack.argtypes = [C.c_float] * 3
         l.oracle_sky.restype = None
@@ -138,6 +142,23 @@ def sqrt_div(a, b):
     q = np.empty_like(a)
     lib().oracle_sqrt_div(a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data)
     return s, q
+
+
+def inv_sqrt(x):
+    """The arithmetic contract's reciprocal square root (what normalize() multiplies by)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().oracle_inv_sqrt(x.size, x.ctypes.data, out.ctypes.data)
+    return out
+
+
+def inv_sqrt_step(x, estimate):
+    """The Newton-Raphson step of the contract's reciprocal square root, from a caller-chosen estimate."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    estimate = np.ascontiguousarray(estimate, dtype=np.float32)
+    out = np.empty_like(x)
+    lib().oracle_inv_sqrt_step(x.size, x.ctypes.data, estimate.ctypes.data, out.ctypes.data)
+    return out
 
 
 def hits_box(origin, direction, center, extents):

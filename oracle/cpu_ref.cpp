@@ -14,15 +14,15 @@
 //   pixel addressing ............ src/image.hpp:143-159
 //
 // The vector/ray arithmetic itself lives in marzer/muu (absent offline).  The formulas chosen for it are
-// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v2": v1's floating-point rules + per-pixel keyed
-// random streams) is this project's own and is what
+// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v3": v1's floating-point rules + per-pixel keyed
+// random streams (v2) + normalize()'s reciprocal square root in one step (v3)) is this project's own and is what
 // the GPU kernels reproduce bit for bit.  The reference is built with -ffast-math -ffp-contract=fast
 // (meson.build:153-160), so it defines no operation order of its own.
 //
-// Arithmetic contract (v1 and v2) — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
+// Arithmetic contract — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
 // no contraction or reassociation except the fmaf() written out here; sqrtf and '/' are correctly rounded:
 //   dot(a,b)          = fmaf(a.z,b.z, fmaf(a.y,b.y, a.x*b.x))
-//   normalize(v)      = v * (1.0f / sqrtf(dot(v,v)))            (one division, three products)
+//   normalize(v)      = v * inv_sqrt(dot(v,v))                  (inv_sqrt below; three products)
 //   direction(a,b)    = normalize(b - a)
 //   at(ray,t)         = fmaf(d, t, o) per component
 //   lerp(a,b,t)       = fmaf(b - a, t, a) per component
@@ -61,9 +61,40 @@ namespace
 
 	inline float dot(vec3 a, vec3 b) { return std::fmaf(a.z, b.z, std::fmaf(a.y, b.y, a.x * b.x)); }
 
+	// Contract v3: normalize()'s reciprocal square root is ONE Newton-Raphson step in binary32, residual computed exactly,
+	// from 1/sqrt(x) truncated toward zero (taken through binary64: a deterministic IEEE expression, no hardware estimate).
+	// It is the correctly rounded 1/sqrt(x) for every significand but x = 4^k * (1 - 2^-23), which gives 2^-k
+	// (tests/test_oracle_kat.py checks both statements over every significand).  muu's normalize() is not readable here
+	// (call sites: mg_ray_tracer.cpp:85,120,138; random.hpp:64) and the reference is built -ffast-math anyway.
+	inline float inv_sqrt_step(float x, float y) // the Newton-Raphson step from the estimate y
+	{
+		const float t = x * y;
+		const float dt = std::fmaf(x, y, -t); // t + dt == x * y exactly
+		const float e = std::fmaf(-dt, y, std::fmaf(-t, y, 1.0f)); // the residual 1 - x*y*y
+		return std::fmaf(0.5f * y, e, y);
+	}
+
+	inline float inv_sqrt(float x)
+	{
+		const double exact = 1.0 / std::sqrt(static_cast<double>(x));
+		float y = static_cast<float>(exact);
+		uint32_t bits;
+		std::memcpy(&bits, &x, 4);
+		if (!((bits - 0x00800000u) < (0x7F800000u - 0x00800000u)))
+			return y; // zero, subnormal, negative, infinite, NaN: the plain quotient
+		if (static_cast<double>(y) > exact) // toward zero
+		{
+			uint32_t yb;
+			std::memcpy(&yb, &y, 4);
+			yb -= 1u;
+			std::memcpy(&y, &yb, 4);
+		}
+		return inv_sqrt_step(x, y);
+	}
+
 	inline vec3 normalize(vec3 v)
 	{
-		const float inv = 1.0f / std::sqrt(dot(v, v));
+		const float inv = inv_sqrt(dot(v, v));
 		return v * inv;
 	}
 
@@ -760,6 +791,18 @@ extern "C" void oracle_sqrt_div(uint32_t n, const float* a, const float* b, floa
 		out_sqrt[i] = std::sqrt(a[i]);
 		out_div[i] = a[i] / b[i];
 	}
+}
+
+extern "C" void oracle_inv_sqrt(uint32_t n, const float* x, float* out)
+{
+	for (uint32_t i = 0; i < n; i++)
+		out[i] = inv_sqrt(x[i]);
+}
+
+extern "C" void oracle_inv_sqrt_step(uint32_t n, const float* x, const float* estimate, float* out)
+{
+	for (uint32_t i = 0; i < n; i++)
+		out[i] = inv_sqrt_step(x[i], estimate[i]);
 }
 
 extern "C" uint32_t oracle_pack(float r, float g, float b)

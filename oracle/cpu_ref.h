@@ -80,6 +80,8 @@ void oracle_closest_hit(const rt_hip_scene* scene,
 						uint32_t* out_index,
 						float* out_normal);
 void oracle_sqrt_div(uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
+void oracle_inv_sqrt(uint32_t n, const float* x, float* out); /* the contract's reciprocal square root (normalize), cpu_ref.cpp inv_sqrt */
+void oracle_inv_sqrt_step(uint32_t n, const float* x, const float* estimate, float* out); /* its Newton-Raphson step alone, from a given estimate */
 uint32_t oracle_pack(float r, float g, float b);			   /* rt::colour{vec3} -> uint32, colour.hpp:63-65,101-106 */
 void oracle_sky(float dir_y, float* out_rgb);				   /* mg_ray_tracer.cpp:164 */
 /* sm_ray_tracer.cpp:181-219: direction chosen by dielectric_scatter for the uniform number u; also the reflect probability */

@@ -3,7 +3,7 @@
 Product code only.  The CPU oracle is test infrastructure and lives in ``oracle/`` (never imported from here).
 """
 from .capi import RtHipError, RtHipPartition, RtHipScene, RtHipStats  # noqa: F401
-from .renderer import HipRayTracer, device_count, local_rows, padded_local_rows, unique_id  # noqa: F401
+from .renderer import HipRayTracer, device_count, local_rows, padded_local_rows, scene_check, unique_id  # noqa: F401
 from .scene import Scene, SceneError, scene_from_arrays  # noqa: F401
 
 __all__ = [
@@ -17,6 +17,7 @@ __all__ = [
     "device_count",
     "local_rows",
     "padded_local_rows",
+    "scene_check",
     "scene_from_arrays",
     "unique_id",
 ]

@@ -16,7 +16,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 
-RT_HIP_ABI_VERSION = 3
+RT_HIP_ABI_VERSION = 4
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
@@ -25,8 +25,11 @@ RT_HIP_FLAG_SM_MATERIALS = 1 << 3
 RT_HIP_FLAG_PREVIEW = 1 << 4
 RT_HIP_FLAG_FORCE_STREAMED = 1 << 5
 RT_HIP_FLAG_FAST = 1 << 6
+RT_HIP_FLAG_STATS = 1 << 7
 RT_HIP_MULTI_PEER_COPY = 1 << 0
 RT_HIP_MULTI_DIRECT_FRAME = 1 << 1
+RT_HIP_TRANSPORT_NONE, RT_HIP_TRANSPORT_RCCL_GATHER, RT_HIP_TRANSPORT_PEER_COPY, RT_HIP_TRANSPORT_DIRECT_FRAME = 0, 1, 2, 3
+TRANSPORT_NAMES = {0: "none", 1: "rccl_gather", 2: "peer_copy", 3: "direct_frame"}
 KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview", 5: "streamed"}
 
 STATUS_NAMES = {
@@ -36,6 +39,7 @@ STATUS_NAMES = {
     3: "RT_HIP_RUNTIME_ERROR",
     4: "RT_HIP_NO_SCENE",
     5: "RT_HIP_UNSUPPORTED",
+    6: "RT_HIP_TIMEOUT",
 }
 
 c_float_p = C.POINTER(C.c_float)
@@ -105,6 +109,26 @@ class RtHipStats(C.Structure):
         return d
 
 
+class RtHipPhases(C.Structure):
+    """``rt_hip_phases`` (include/rt_hip.h)."""
+
+    _fields_ = [
+        ("render_ms", C.c_float),
+        ("gather_ms", C.c_float),
+        ("assemble_ms", C.c_float),
+        ("copy_ms", C.c_float),
+        ("host_issue_ms", C.c_float),
+        ("host_wait_ms", C.c_float),
+        ("transport", C.c_uint32),
+        ("scene_resident", C.c_uint32),
+    ]
+
+    def as_dict(self) -> dict:
+        d = {name: getattr(self, name) for name, _ in self._fields_}
+        d["transport"] = TRANSPORT_NAMES.get(self.transport, str(self.transport))
+        return d
+
+
 # every symbol include/rt_hip.h declares: (name, restype, argtypes)
 RT_HIP_SYMBOLS = [
     ("rt_hip_abi_version", C.c_uint32, []),
@@ -115,11 +139,14 @@ RT_HIP_SYMBOLS = [
     ("rt_hip_create_multi", C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_uint32]),
     ("rt_hip_unique_id", C.c_int, [C.c_char * 128]),
     ("rt_hip_create_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char * 128]),
+    ("rt_hip_join_ranks", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char * 128, C.c_uint32]),
+    ("rt_hip_comm_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), c_u32_p]),
     ("rt_hip_member_count", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("rt_hip_member_device", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     ("rt_hip_member_stats", C.c_int, [C.c_void_p, C.c_int, C.POINTER(RtHipStats)]),
     ("rt_hip_local_rows", C.c_int, [C.c_uint32, C.POINTER(RtHipPartition), c_u32_p]),
     ("rt_hip_padded_local_rows", C.c_int, [C.c_uint32, C.POINTER(RtHipPartition), c_u32_p]),
+    ("rt_hip_scene_check", C.c_int, [C.POINTER(RtHipScene), C.POINTER(C.c_uint64)]),
     ("rt_hip_scene_upload", C.c_int, [C.c_void_p, C.POINTER(RtHipScene)]),
     (
         "rt_hip_render_device",
@@ -128,6 +155,7 @@ RT_HIP_SYMBOLS = [
     ),
     ("rt_hip_assemble_device", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_hip_stats_fetch", C.c_int, [C.c_void_p, C.POINTER(RtHipStats)]),
+    ("rt_hip_phases_fetch", C.c_int, [C.c_void_p, C.POINTER(RtHipPhases)]),
     (
         "rt_hip_render",
         C.c_int,

@@ -1,5 +1,6 @@
-// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v2"
-// (v2 = v1's floating-point rules with per-pixel keyed random streams).
+// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v3"
+// (v2 = v1's floating-point rules with per-pixel keyed random streams; v3 = v2 with normalize()'s reciprocal square
+// root taken in one step instead of as a rounded square root followed by a rounded reciprocal).
 //
 // Every function here is the gfx950 counterpart of a reference function on the mg_ray_tracer path and produces
 // bit-identical binary32 results to the CPU oracle:
@@ -37,8 +38,8 @@ namespace rt_hip
 	// Inside a band of exponents where no intermediate can overflow or underflow the core of those sequences is
 	// enough.  The functions below take the core when the argument lies in the band and fall back to the general
 	// expansion otherwise (a wave-uniform branch that is practically never taken), so their results are
-	// BIT-IDENTICAL to __builtin_sqrtf(x), 1.0f / x and 1.0f / __builtin_sqrtf(x) for EVERY input; this is checked
-	// on the device over all 2^32 bit patterns by rt_hip_kat_exhaustive_math (tests/test_gpu_parity.py).
+	// BIT-IDENTICAL to __builtin_sqrtf(x), 1.0f / x and the contract's inv_sqrt(x) (below) for EVERY input; this is
+	// checked on the device over all 2^32 bit patterns by rt_hip_kat_exhaustive_math (tests/test_gpu_parity.py).
 #ifdef RT_HIP_FAST_BUILD
 	// ---- contract "v2-fast" (RT_HIP_FLAG_FAST; this translation unit is built a second time with RT_HIP_FAST_BUILD and
 	// -ffp-contract=fast) -------------------------------------------------------------------------------------------
@@ -114,37 +115,61 @@ namespace rt_hip
 		return q;
 	}
 
-	// == 1.0f / __builtin_sqrtf(x): both roundings kept.  (Seeding the reciprocal with the square root's own
-	// reciprocal-square-root estimate instead of v_rcp_f32 saves a transcendental but is NOT exact: it misses the
-	// correctly rounded quotient for the 120 inputs just below an even power of two — exactly what normalising an
-	// already unit-length direction produces — as the exhaustive search showed.)
+	// ---- the reciprocal square root of normalize(): contract v3 -----------------------------------------------------
+	// v2 defined normalize() through 1.0f / sqrtf(x) and kept BOTH roundings: a quarter-rate v_rsq AND a quarter-rate
+	// v_rcp plus six multiply-adds per call.  v3 defines it as ONE Newton-Raphson step in binary32, with the residual
+	// computed exactly, from the truncated reciprocal square root (oracle/cpu_ref.cpp, inv_sqrt):
+	//     y  = 1/sqrt(x) rounded TOWARD ZERO to binary32                  (positive normal x; everything else below)
+	//     t  = x * y                dt = fma(x, y, -t)                     (t + dt == x * y exactly)
+	//     e  = fma(-dt, y, fma(-t, y, 1))                                 (the residual 1 - x*y*y, to 2^-24 of itself)
+	//     r  = fma(0.5f * y, e, y)
+	// r is the correctly rounded 1/sqrt(x) for every significand but one — x = 4^k * (1 - 2^-23), where the first-order
+	// value lands exactly on a rounding midpoint and r is 2^-k (0.5000002 ulp); tests/test_oracle_kat.py checks that over
+	// every significand.  The step squares the seed's error, so from any seed within an ulp of the truth it gives the
+	// same r for all but a handful of significands; that gfx950's v_rsq_f32 estimate gives the definition's r for EVERY
+	// input was established exhaustively (tools/rsqrt_search.hip over the band, profiles/r03/rsqrt_search.txt) and is
+	// re-checked by rt_hip_kat_exhaustive_math on ALL 2^32 inputs on the device the tests run on.
+	__device__ __forceinline__ float inv_sqrt_newton(float x, float y)
+	{
+		const float t = x * y;
+		const float dt = fma(x, y, -t);
+		const float e = fma(-dt, y, fma(-t, y, 1.0f));
+		return fma(0.5f * y, e, y);
+	}
+
+	// the definition itself, for any argument (the rare path of inv_sqrt_rn and the reference of the exhaustive check)
+	__device__ __forceinline__ float inv_sqrt_definition(float x)
+	{
+		const double exact = 1.0 / __builtin_sqrt(static_cast<double>(x));
+		float y = static_cast<float>(exact);
+		if (!((__float_as_uint(x) - 0x00800000u) < (0x7F800000u - 0x00800000u)))
+			return y; // zero, subnormal, negative, infinite, NaN: the plain quotient (inf, NaN, 0 ...)
+		if (static_cast<double>(y) > exact)
+			y = __uint_as_float(__float_as_uint(y) - 1u); // toward zero
+		return inv_sqrt_newton(x, y);
+	}
+
+	// == inv_sqrt_definition(x)
 	__device__ __forceinline__ float inv_sqrt_rn(float x)
 	{
 		const bool fast = in_fast_band(x);
-		float h;
-		const float s = sqrt_core(x, h); // x in the band: s in [2^-30, 2^30), inside the reciprocal's band as well
-		float q = rcp_core(s, __builtin_amdgcn_rcpf(s));
+		float q = inv_sqrt_newton(x, __builtin_amdgcn_rsqf(x)); // out of the band: replaced below
 		if (!fast)
 		{
 			RT_HIP_RARE_PATH();
-			q = 1.0f / __builtin_sqrtf(x);
+			q = inv_sqrt_definition(x);
 		}
 		return q;
 	}
 
 	// inv_sqrt_rn for an argument the CALLER has proved to lie in the band: no check, no fallback
-	__device__ __forceinline__ float inv_sqrt_in_band(float x)
-	{
-		float h;
-		const float s = sqrt_core(x, h);
-		return rcp_core(s, __builtin_amdgcn_rcpf(s));
-	}
+	__device__ __forceinline__ float inv_sqrt_in_band(float x) { return inv_sqrt_newton(x, __builtin_amdgcn_rsqf(x)); }
 
 	// a / b, correctly rounded
 	__device__ __forceinline__ float divide(float a, float b) { return a / b; }
 #endif
 
-	// normalize(v) = v * (1 / sqrt(dot(v,v)))
+	// normalize(v) = v * inv_sqrt(dot(v,v))
 	__device__ __forceinline__ vec3 normalize(vec3 v)
 	{
 		const float inv = inv_sqrt_rn(dot(v, v));

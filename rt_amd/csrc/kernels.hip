@@ -180,6 +180,52 @@ namespace rt_hip
 			}
 		}
 
+		// The streamed kernel's sphere scan: the (center, radius^2) table is read from HBM/L2 with wave-uniform scalar loads,
+		// four spheres = 64 bytes = one s_load_dwordx16.  Every wave of a CU walks the 1.6 MB table at its own position, so
+		// the 16 KB scalar cache holds next to nothing of it (SQC_DCACHE: 29 % hits at 100 000 spheres,
+		// profiles/r03/config5_streamed/) and most loads come from L2.  The load of group g+1 is therefore issued BEFORE
+		// group g is probed (two register sets, the loop unrolled by two so that no set is ever copied): the wave has 48
+		// vector instructions to issue while its next 64 bytes are on their way.
+		__device__ __forceinline__ void probe_group(candidate& best, vec3 o, vec3 d, float4 s0, float4 s1, float4 s2, float4 s3, uint32_t first_index)
+		{
+			const sphere_probe p0 = probe_sphere(o, d, s0);
+			const sphere_probe p1 = probe_sphere(o, d, s1);
+			const sphere_probe p2 = probe_sphere(o, d, s2);
+			const sphere_probe p3 = probe_sphere(o, d, s3);
+			const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0.pos), m1 = __builtin_amdgcn_ballot_w64(p1.pos);
+			const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2.pos), m3 = __builtin_amdgcn_ballot_w64(p3.pos);
+			if ((m0 | m1 | m2 | m3) != 0)
+			{
+				finish_sphere(best, p0, s0.w, first_index, m0);
+				finish_sphere(best, p1, s1.w, first_index + 1, m1);
+				finish_sphere(best, p2, s2.w, first_index + 2, m2);
+				finish_sphere(best, p3, s3.w, first_index + 3, m3);
+			}
+		}
+
+		__device__ __forceinline__ void scan_streamed_spheres(candidate& best, vec3 o, vec3 d, const float4* __restrict__ table, uint32_t count)
+		{
+			const uint32_t groups = count >> 2;
+			if (groups)
+			{
+				float4 a0 = table[0], a1 = table[1], a2 = table[2], a3 = table[3];
+				uint32_t g = 0;
+				for (; g + 2 <= groups; g += 2)
+				{
+					const float4* const b = table + (g + 1) * 4;
+					const float4 b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+					probe_group(best, o, d, a0, a1, a2, a3, g * 4);
+					const float4* const a = table + (g + 2 < groups ? g + 2 : groups - 1) * 4; // (past the end: the last group again, unused)
+					a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3];
+					probe_group(best, o, d, b0, b1, b2, b3, (g + 1) * 4);
+				}
+				if (g < groups)
+					probe_group(best, o, d, a0, a1, a2, a3, g * 4);
+			}
+			for (uint32_t i = groups * 4; i < count; i++)
+				test_sphere(best, o, d, table[i], i);
+		}
+
 		// cooperative copy of `count` primitives starting at `first` from the SoA columns into float4 LDS slots;
 		// lane i of the workgroup reads element first+i of each column (coalesced), radius is squared on the way in
 		__device__ __forceinline__ void stage_spheres(float4* lds, const device_scene& s, uint32_t first, uint32_t count)
@@ -576,7 +622,12 @@ namespace rt_hip
 						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
 						const float4* const primitives = NS == 0 ? lds : geometry;
 						scan_lds<false>(planes, st.origin, st.dir, primitives + s.n_spheres, s.n_planes, 0);
-						scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
+#ifndef RT_HIP_NO_STREAM_PREFETCH
+						if (NS == -2)
+							scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
+						else
+#endif
+							scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
 						uint32_t index;
 						kind = select_hit(spheres, planes, distance, index);
 						fetch_hit<SM>(s, st.origin, st.dir, kind, distance, index, normal, shading, scatter_kind);
@@ -982,12 +1033,18 @@ namespace rt_hip
 		}
 
 		// ---- multi-GPU assemble: rank-major compact stripes -> frame ------------------------------------------------
-		// `width` counts 32-bit words per row: pixels for the RGBA8888 frame, 3 x pixels for the float mean
+		// `width` counts 32-bit words per row: pixels for the RGBA8888 frame, 3 x pixels for the float mean.
+		// Rows of ranks below `first_rank` are left alone (the root's own stripes, when its kernel has already stored them
+		// straight into the frame).  TO_HOST: the frame is the caller's page-locked back buffer — system-scope stores, written
+		// through at once, so that the words cross PCIe while the kernel runs instead of behind its end-of-kernel write-back
+		// (finish_pixel has the measurement).
+		template <bool TO_HOST>
 		__global__ __launch_bounds__(block_threads) void assemble_stripes(uint32_t width,
 																		  uint32_t height,
 																		  uint32_t world,
 																		  uint32_t stripe_rows,
 																		  uint32_t padded_local_rows,
+																		  uint32_t first_rank,
 																		  const uint32_t* __restrict__ gathered,
 																		  uint32_t* __restrict__ frame)
 		{
@@ -997,8 +1054,14 @@ namespace rt_hip
 				return;
 			const uint32_t stripe = y / stripe_rows;
 			const uint32_t rank = stripe % world;
+			if (rank < first_rank) // (block-uniform: a block lies within one row)
+				return;
 			const uint32_t local_row = (stripe / world) * stripe_rows + (y % stripe_rows);
-			frame[static_cast<size_t>(y) * width + x] = gathered[(static_cast<size_t>(rank) * padded_local_rows + local_row) * width + x];
+			const uint32_t word = gathered[(static_cast<size_t>(rank) * padded_local_rows + local_row) * width + x];
+			if (TO_HOST)
+				__hip_atomic_store(&frame[static_cast<size_t>(y) * width + x], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			else
+				frame[static_cast<size_t>(y) * width + x] = word;
 		}
 
 		// ---- known-answer kernels -----------------------------------------------------------------------------------
@@ -1083,7 +1146,8 @@ namespace rt_hip
 		}
 
 		// every one of the 2^32 binary32 bit patterns through sqrt_rn / rcp_rn / inv_sqrt_rn against hipcc's general
-		// correctly rounded expansions; result[2k] = mismatches, result[2k+1] = smallest mismatching input + 1
+		// correctly rounded expansions (inv_sqrt_rn: against the contract's definition, evaluated through binary64);
+		// result[2k] = mismatches, result[2k+1] = smallest mismatching input + 1
 		__device__ __forceinline__ bool same_float(float a, float b)
 		{
 			return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
@@ -1100,7 +1164,7 @@ namespace rt_hip
 				const float x = __uint_as_float(bits);
 				const bool ok[3] = { same_float(sqrt_rn(x), __builtin_sqrtf(x)),
 									 same_float(rcp_rn(x), 1.0f / x),
-									 same_float(inv_sqrt_rn(x), 1.0f / __builtin_sqrtf(x)) };
+									 same_float(inv_sqrt_rn(x), inv_sqrt_definition(x)) };
 #pragma unroll
 				for (int f = 0; f < 3; f++)
 					if (!ok[f])
@@ -1139,7 +1203,12 @@ namespace rt_hip
 			{
 				// persistent launch: exactly what the device keeps resident (surplus workgroups would only find the queue dry).
 				// The answer is remembered per context (= per device and host thread of use), per kernel and LDS size.
-				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM)];
+#ifdef RT_HIP_FAST_BUILD
+				constexpr bool fast_arithmetic = true;
+#else
+				constexpr bool fast_arithmetic = false;
+#endif
+				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM, fast_arithmetic)];
 				if (known.lds_bytes != lds_bytes || known.per_cu < 1)
 				{
 					int per_cu = 0;
@@ -1307,10 +1376,15 @@ namespace rt_hip
 						 uint32_t padded_local_rows,
 						 const uint32_t* d_gathered,
 						 uint32_t* d_frame,
+						 uint32_t first_rank,
+						 bool frame_is_host_memory,
 						 hipStream_t stream)
 	{
 		const dim3 grid((width + block_threads - 1) / block_threads, height);
-		hipLaunchKernelGGL(assemble_stripes, grid, dim3(block_threads), 0, stream, width, height, world, stripe_rows, padded_local_rows, d_gathered, d_frame);
+		if (frame_is_host_memory)
+			hipLaunchKernelGGL(assemble_stripes<true>, grid, dim3(block_threads), 0, stream, width, height, world, stripe_rows, padded_local_rows, first_rank, d_gathered, d_frame);
+		else
+			hipLaunchKernelGGL(assemble_stripes<false>, grid, dim3(block_threads), 0, stream, width, height, world, stripe_rows, padded_local_rows, first_rank, d_gathered, d_frame);
 	}
 
 	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream)

@@ -123,13 +123,11 @@ namespace rt_hip
 			int per_cu = 0;
 		};
 		entry persistent[6]; // { tiled, streamed } x { mg, sm scatter table, fast arithmetic }
-		static constexpr unsigned slot(bool streamed, bool sm)
+		// one definition for both builds of kernels.hip (the parity contract and RT_HIP_FAST_BUILD), which are linked into
+		// one library: the build says which arithmetic it is through the argument (the fast build has no sm scatter table)
+		static constexpr unsigned slot(bool streamed, bool sm, bool fast_arithmetic)
 		{
-#ifdef RT_HIP_FAST_BUILD
-			return (streamed ? 3u : 0u) + 2u; // (the fast build has no sm scatter table)
-#else
-			return (streamed ? 3u : 0u) + (sm ? 1u : 0u);
-#endif
+			return (streamed ? 3u : 0u) + (fast_arithmetic ? 2u : (sm ? 1u : 0u));
 		}
 	};
 
@@ -171,6 +169,8 @@ namespace rt_hip
 						 uint32_t padded_local_rows,
 						 const uint32_t* d_gathered,
 						 uint32_t* d_frame,
+						 uint32_t first_rank,		// rows of ranks below this one are left alone (already in the frame)
+						 bool frame_is_host_memory, // the caller's page-locked back buffer: system-scope stores
 						 hipStream_t stream);
 
 	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream);

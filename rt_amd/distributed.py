@@ -134,3 +134,65 @@ class DistributedFrame:
         if gathered is None:
             return None
         return assemble(gathered, self.width, self.height, self.stripe_rows, tracer=tracer, stream=stream.cuda_stream)
+
+
+# ---- one process per GPU: bringing up the module's own multi-GPU renderer without a way to hang ---------------------------
+
+
+def all_agree(ok: bool, device="cpu", group=None) -> bool:
+    """True iff `ok` holds on EVERY rank (one all_reduce(MIN) of the process group the launcher already has)."""
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+def negotiate_rank_renderer(create, join, make_id, vote_device="cpu", group=None, log=None):
+    """Every rank of the process group ends up with a joined rank of ONE renderer — or every rank ends up with None.
+
+    rt_hip_create_rank is collective (ncclCommInitRank): a rank that fails in front of it — no device, wrong
+    architecture, out of memory — would leave the others waiting in it.  So the part that can fail alone comes first, the
+    ranks VOTE, and only then does anybody enter the collective call; that call carries a deadline of its own
+    (rt_hip_join_ranks: RT_HIP_TIMEOUT), and the ranks vote once more on its outcome.
+
+        create()            -> a context of this rank's own (HipRayTracer(device=...)); may raise
+        make_id()           -> the 128-byte RCCL id; called on rank 0 only; may raise
+        join(tracer, id)    -> tracer.join_ranks(rank, world, id, timeout_ms); collective; may raise
+
+    Returns (tracer, None) on every rank, or (None, reason) on every rank (contexts already created are closed).
+    """
+    rank = dist.get_rank(group)
+    say = log or (lambda message: None)
+    tracer, problem = None, None
+    try:
+        tracer = create()
+    except Exception as e:  # noqa: BLE001 - any failure of this rank is a "no" in the vote
+        problem = f"rank {rank}: create failed: {e}"
+        say(problem)
+    if not all_agree(tracer is not None, vote_device, group):
+        if tracer is not None:
+            tracer.close()
+        return None, problem or "another rank could not create its context"
+
+    ids = [None]
+    if rank == 0:
+        try:
+            ids[0] = make_id()
+        except Exception as e:  # noqa: BLE001
+            problem = f"rank 0: unique id failed: {e}"
+            say(problem)
+    dist.broadcast_object_list(ids, src=0, group=group)
+    if ids[0] is None:  # every rank sees the same None: nobody enters the collective call
+        tracer.close()
+        return None, problem or "rank 0 could not make the RCCL id"
+
+    joined = False
+    try:
+        join(tracer, ids[0])
+        joined = True
+    except Exception as e:  # noqa: BLE001
+        problem = f"rank {rank}: join failed: {e}"
+        say(problem)
+    if not all_agree(joined, vote_device, group):
+        tracer.close()
+        return None, problem or "another rank could not join the communicator"
+    return tracer, None

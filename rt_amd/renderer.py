@@ -19,7 +19,7 @@ import ctypes as C
 import numpy as np
 
 from . import capi
-from .capi import RtHipPartition, RtHipScene, RtHipStats, check
+from .capi import RtHipPartition, RtHipPhases, RtHipScene, RtHipStats, check
 
 
 def local_rows(height: int, rank: int, world: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS) -> int:
@@ -31,6 +31,13 @@ def local_rows(height: int, rank: int, world: int, stripe_rows: int = capi.RT_HI
 def padded_local_rows(height: int, world: int, stripe_rows: int = capi.RT_HIP_DEFAULT_STRIPE_ROWS) -> int:
     out = C.c_uint32()
     check(capi.hip_lib().rt_hip_padded_local_rows(height, C.byref(RtHipPartition(0, world, stripe_rows)), C.byref(out)))
+    return out.value
+
+
+def scene_check(scene: RtHipScene) -> int:
+    """rt_hip_scene_check: validate the columns as rt_hip_render would and return their fingerprint (pure host code)."""
+    out = C.c_uint64()
+    check(capi.hip_lib().rt_hip_scene_check(C.byref(scene), C.byref(out)))
     return out.value
 
 
@@ -76,6 +83,26 @@ class HipRayTracer:
             self.device = devices[0]
             self.devices = list(devices)
 
+    def join_ranks(self, rank: int, world: int, unique_id: bytes, timeout_ms: int = 0) -> None:
+        """rt_hip_join_ranks: the collective half of rt_hip_create_rank, on a context made by plain ``HipRayTracer(device)``
+        — after the launcher has made sure that EVERY rank holds one.  Raises RtHipError (RT_HIP_TIMEOUT after `timeout_ms`;
+        the tracer stays a usable single-GPU tracer then)."""
+        assert len(unique_id) == 128
+        check(self._lib.rt_hip_join_ranks(self._ctx, rank, world, (C.c_char * 128).from_buffer_copy(unique_id), timeout_ms))
+        self.rank, self.world = rank, world
+
+    def comm_info(self, member: int = 0) -> dict:
+        """What RCCL reports about the communicator member `member` talks through (rt_hip_comm_info)."""
+        ranks, rank, device, transport = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
+        check(self._lib.rt_hip_comm_info(self._ctx, member, C.byref(ranks), C.byref(rank), C.byref(device), C.byref(transport)))
+        return {"ranks": ranks.value, "rank": rank.value, "device": device.value, "transport": capi.TRANSPORT_NAMES.get(transport.value, str(transport.value))}
+
+    def phases(self) -> dict:
+        """Where the time of the most recent render() went (rt_hip_phases_fetch)."""
+        phases = RtHipPhases()
+        check(self._lib.rt_hip_phases_fetch(self._ctx, C.byref(phases)))
+        return phases.as_dict()
+
     def close(self) -> None:
         ctx, self._ctx = getattr(self, "_ctx", None), None
         if ctx:
@@ -90,19 +117,22 @@ class HipRayTracer:
         self.close()
 
     # ---- drop-in ------------------------------------------------------------------------------------------
-    def render(self, scene: RtHipScene, width: int, height: int, seed: int = 1, flags: int = 0, want_rgb: bool = False, out: np.ndarray | None = None):
+    def render(self, scene: RtHipScene, width: int, height: int, seed: int = 1, flags: int = 0, want_rgb: bool = False, out: np.ndarray | None = None, stats: bool = True):
         """rt_hip_render: returns (rgba8 uint32[H, W], rgb float32[H, W, 3] or None, stats dict).
 
-        `out`: a uint32[H, W] array to render into (like rt's persistent back buffer); a fresh one otherwise."""
+        `out`: a uint32[H, W] array to render into (like rt's persistent back buffer); a fresh one otherwise.
+        `stats=False`: the call as the plug-in makes it (stats == NULL): nothing but the launch and the wait is enqueued;
+        the returned dict is empty."""
+        want_stats = stats
+        stats = RtHipStats()
+        stats_arg = C.byref(stats) if want_stats else None
         if self.rank != 0:  # a rank whose rank 0 lives in another process renders and sends; it has no frame of its own
-            stats = RtHipStats()
             rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
-            check(self._lib.rt_hip_render(self._ctx, C.byref(scene), None, width, height, seed, flags, rgb.ctypes.data if rgb is not None else None, C.byref(stats)))
-            return None, None, stats.as_dict()
+            check(self._lib.rt_hip_render(self._ctx, C.byref(scene), None, width, height, seed, flags, rgb.ctypes.data if rgb is not None else None, stats_arg))
+            return None, None, stats.as_dict() if want_stats else {}
         rgba = out if out is not None else np.empty((height, width), dtype=np.uint32)
         assert rgba.dtype == np.uint32 and rgba.shape == (height, width) and rgba.flags.c_contiguous
         rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
-        stats = RtHipStats()
         check(
             self._lib.rt_hip_render(
                 self._ctx,
@@ -113,10 +143,10 @@ class HipRayTracer:
                 seed,
                 flags,
                 rgb.ctypes.data if rgb is not None else None,
-                C.byref(stats),
+                stats_arg,
             )
         )
-        return rgba, rgb, stats.as_dict()
+        return rgba, rgb, stats.as_dict() if want_stats else {}
 
     def forget_frame(self) -> None:
         """Drop the page-lock on the back buffer last rendered into with RT_HIP_FLAG_PERSISTENT_FRAME."""

@@ -1,0 +1,230 @@
+// tests/native/soagen_columns.cpp — SURVEY.md §8 row a-8 against the reference's REAL container runtime.
+//
+// The C ABI takes the raw column pointers of rt::spheres / rt::planes / rt::materials (reference src/soa.hpp:177-199).
+// Everything else in this repository hands it pointers from this project's own mirror (rt_amd/host/soa.hpp) or from numpy.
+// This program builds the tables with the reference's vendored soagen runtime itself — vendor/soagen.hpp is std-only
+// (:1231-1265) and is compiled here IN PLACE from /root/reference (build container only; nothing of it is copied, and
+// the test is skipped where the reference tree is absent) — with the column types, alignments and order of
+// src/soa.toml:6-33 as src/soa.hpp:155-199 instantiates them (32-byte aligned float / unsigned columns, whose capacity
+// soagen rounds up to aligned_stride = 8 rows: soagen.hpp:3777,7075-7082), fills them, and hands the pointers the
+// accessors return to
+//   * rt_hip_scene_check — the product's own pointer / index check and column fingerprint (pure host code), and
+//   * the oracle's renderer,
+// once as they are and once with everything behind size() POISONED (NaN floats, 0xFFFFFFFF indices).  "Never read past
+// size()" then means: same verdict, same fingerprint, same frame — and the same as from plain packed std::vectors.
+//
+// build (tests/test_soagen_columns.py does it): g++ -std=c++20 -O1 -I/root/reference/vendor -Iinclude -Ioracle
+//            tests/native/soagen_columns.cpp -o <out> -Lrt_amd/lib -lrt_hip -Loracle -loracle -Wl,-rpath,<both>
+#include <soagen.hpp>
+
+#include "cpu_ref.h"
+#include "rt_hip.h"
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+namespace
+{
+	// stand-ins for the muu value types of column 0 (16 bytes of floats each; never read by the plug-in or the oracle)
+	struct sphere_value
+	{
+		float center[3], radius;
+	};
+	struct plane_value
+	{
+		float normal[3], d;
+	};
+	struct alignas(16) colour_value // rt::colour: four floats (src/colour.hpp:17-57)
+	{
+		float r, g, b, a;
+	};
+
+	// src/soa.hpp:155-199 (generated from src/soa.toml:6-33)
+	using materials_traits = soagen::table_traits<soagen::column_traits<std::string>,
+												  soagen::column_traits<uint32_t>, // enum class material_type : unsigned-sized
+												  soagen::column_traits<colour_value>,
+												  soagen::column_traits<float>,
+												  soagen::column_traits<float>>;
+	using planes_traits = soagen::table_traits<soagen::column_traits<plane_value>,
+											   soagen::column_traits<unsigned, soagen::max(std::size_t{ 32u }, alignof(unsigned))>,
+											   soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+											   soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+											   soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+											   soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>>;
+	using spheres_traits = soagen::table_traits<soagen::column_traits<sphere_value>,
+												soagen::column_traits<unsigned, soagen::max(std::size_t{ 32u }, alignof(unsigned))>,
+												soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+												soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+												soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>,
+												soagen::column_traits<float, soagen::max(std::size_t{ 32u }, alignof(float))>>;
+	using materials_table = soagen::table<materials_traits, soagen::allocator>;
+	using planes_table = soagen::table<planes_traits, soagen::allocator>;
+	using spheres_table = soagen::table<spheres_traits, soagen::allocator>;
+
+	int failures = 0;
+#define EXPECT(cond)                                                                                                   \
+	do                                                                                                                 \
+	{                                                                                                                  \
+		if (!(cond))                                                                                                   \
+		{                                                                                                              \
+			std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);                                              \
+			failures++;                                                                                                \
+		}                                                                                                              \
+	}                                                                                                                  \
+	while (false)
+
+	struct frame
+	{
+		std::vector<uint32_t> rgba;
+		std::vector<float> rgb;
+		oracle_stats stats{};
+	};
+
+	frame render(const rt_hip_scene& s, uint32_t w, uint32_t h)
+	{
+		frame f;
+		f.rgba.assign(static_cast<size_t>(w) * h, 0);
+		f.rgb.assign(static_cast<size_t>(w) * h * 3, 0.0f);
+		const int rc = oracle_render(&s, w, h, 5, 0, nullptr, f.rgba.data(), f.rgb.data(), 2, &f.stats);
+		EXPECT(rc == 0);
+		return f;
+	}
+
+	// a pinhole camera at (0, 1, 4) looking down -Z, vertical field of view pi/4, near 0.01, far 1000 (src/camera.hpp:54-58):
+	// ndc (x, y, depth) -> camera space (a t x, t y, -1) / w with w = (1 - depth)/near + depth/far, then + eye
+	void camera(rt_hip_scene& s, uint32_t w, uint32_t h)
+	{
+		const float t = std::tan(3.14159265f / 8.0f), aspect = static_cast<float>(w) / static_cast<float>(h), n = 0.01f, f = 1000.0f;
+		const float m[16] = { aspect * t, 0, 0, 0, /**/ 0, t, 0, 0, /**/ 0, 0, 0, -1, /**/ 0, 0, 1.0f / f - 1.0f / n, 1.0f / n };
+		std::memcpy(s.inverse_view_projection, m, sizeof(m));
+		const float eye[3] = { 0.0f, 1.0f, 4.0f };
+		for (int r = 0; r < 3; r++)
+			for (int c = 0; c < 4; c++)
+				s.inverse_view_projection[r * 4 + c] += eye[r] * s.inverse_view_projection[3 * 4 + c];
+	}
+}
+
+int main()
+{
+	materials_table materials;
+	planes_table planes;
+	spheres_table spheres;
+
+	// rows as src/scene.cpp:540-615 pushes them: the AoS value and the split float columns side by side
+	const int n_materials = 5, n_planes = 2, n_spheres = 11; // 11 and 2 rows: capacities 16 and 8 => 5 and 6 padding rows
+	for (int m = 0; m < n_materials; m++)
+		materials.emplace_back(std::string("material ") + std::to_string(m), static_cast<uint32_t>(m % 3 == 1 ? 1 : (m == 4 ? 2 : 0)),
+							   colour_value{ 0.3f + 0.15f * static_cast<float>(m), 0.9f - 0.1f * static_cast<float>(m), 0.5f, 1.0f }, 0.05f * static_cast<float>(m + 1),
+							   m % 3 == 1 ? 0.8f : 0.5f);
+	planes.emplace_back(plane_value{ { 0, 1, 0 }, 0.0f }, 0u, 0.0f, 1.0f, 0.0f, 0.0f);
+	planes.emplace_back(plane_value{ { 0, 0, 1 }, 6.0f }, 3u, 0.0f, 0.0f, 1.0f, 6.0f);
+	for (int i = 0; i < n_spheres; i++)
+	{
+		const float cx = -2.5f + 0.5f * static_cast<float>(i), cy = 0.4f + 0.1f * static_cast<float>(i % 3), cz = -0.3f * static_cast<float>(i % 4), r = 0.25f + 0.02f * static_cast<float>(i);
+		spheres.emplace_back(sphere_value{ { cx, cy, cz }, r }, static_cast<unsigned>(i % n_materials), cx, cy, cz, r);
+	}
+	EXPECT(spheres.size() == static_cast<size_t>(n_spheres) && planes.size() == static_cast<size_t>(n_planes));
+	// the layout facts §8 a-8 states: 32-byte aligned columns, capacity padded to whole 8-row strides
+	EXPECT(spheres_table::aligned_stride == 8u && planes_table::aligned_stride == 8u);
+	EXPECT(spheres.capacity() >= 16u && spheres.capacity() % 8u == 0u && planes.capacity() >= 8u && planes.capacity() % 8u == 0u);
+	EXPECT(reinterpret_cast<uintptr_t>(spheres.column<2>()) % 32u == 0u && reinterpret_cast<uintptr_t>(spheres.column<5>()) % 32u == 0u);
+	EXPECT(reinterpret_cast<uintptr_t>(spheres.column<1>()) % 32u == 0u && reinterpret_cast<uintptr_t>(planes.column<5>()) % 32u == 0u);
+
+	const uint32_t width = 96, height = 54;
+	rt_hip_scene s{};
+	// what shim/hip_ray_tracer.cpp does with scene.spheres.center_x() ... (the named accessors are column<N>())
+	s.n_spheres = static_cast<uint32_t>(spheres.size());
+	s.sphere_material = spheres.column<1>();
+	s.sphere_center_x = spheres.column<2>();
+	s.sphere_center_y = spheres.column<3>();
+	s.sphere_center_z = spheres.column<4>();
+	s.sphere_radius = spheres.column<5>();
+	s.n_planes = static_cast<uint32_t>(planes.size());
+	s.plane_material = planes.column<1>();
+	s.plane_normal_x = planes.column<2>();
+	s.plane_normal_y = planes.column<3>();
+	s.plane_normal_z = planes.column<4>();
+	s.plane_d = planes.column<5>();
+	s.n_materials = static_cast<uint32_t>(materials.size());
+	s.material_type = materials.column<1>();
+	s.material_albedo = &materials.column<2>()->r;
+	s.material_roughness = materials.column<3>();
+	s.material_reflectivity = materials.column<4>();
+	s.samples_per_pixel = 3;
+	s.max_bounces = 6;
+	camera(s, width, height);
+
+	uint64_t print_clean = 0;
+	EXPECT(rt_hip_scene_check(&s, &print_clean) == RT_HIP_OK);
+	const frame clean = render(s, width, height);
+	EXPECT(clean.stats.segments > static_cast<uint64_t>(width) * height * 3); // something was hit: paths continue
+	EXPECT(clean.stats.sphere_tests == clean.stats.segments * static_cast<uint64_t>(n_spheres));
+
+	// poison every row between size() and capacity() of every column the plug-in is given
+	const float nan = std::numeric_limits<float>::quiet_NaN();
+	for (size_t i = spheres.size(); i < spheres.capacity(); i++)
+	{
+		spheres.column<1>()[i] = 0xFFFFFFFFu;
+		spheres.column<2>()[i] = spheres.column<3>()[i] = spheres.column<4>()[i] = nan;
+		spheres.column<5>()[i] = 1.0e30f; // a sphere that would swallow the scene
+	}
+	for (size_t i = planes.size(); i < planes.capacity(); i++)
+	{
+		planes.column<1>()[i] = 0xFFFFFFFFu;
+		planes.column<2>()[i] = planes.column<3>()[i] = planes.column<4>()[i] = planes.column<5>()[i] = nan;
+	}
+	for (size_t i = materials.size(); i < materials.capacity(); i++)
+	{
+		materials.column<1>()[i] = 0xFFFFFFFFu;
+		materials.column<2>()[i] = colour_value{ nan, nan, nan, nan };
+		materials.column<3>()[i] = materials.column<4>()[i] = nan;
+	}
+	uint64_t print_poisoned = 0;
+	EXPECT(rt_hip_scene_check(&s, &print_poisoned) == RT_HIP_OK); // an index read behind size() would be "out-of-range"
+	EXPECT(print_poisoned == print_clean);						   // a byte read behind size() would move the fingerprint
+	const frame poisoned = render(s, width, height);
+	EXPECT(poisoned.rgba == clean.rgba);
+	EXPECT(std::memcmp(poisoned.rgb.data(), clean.rgb.data(), clean.rgb.size() * sizeof(float)) == 0);
+	EXPECT(poisoned.stats.segments == clean.stats.segments);
+
+	// the same rows from plain packed vectors: the container adds nothing but alignment and padding
+	std::vector<float> cx, cy, cz, cr, pnx, pny, pnz, pd, albedo, rough, refl;
+	std::vector<uint32_t> cm, pm, mt;
+	for (size_t i = 0; i < spheres.size(); i++)
+		cx.push_back(spheres.column<2>()[i]), cy.push_back(spheres.column<3>()[i]), cz.push_back(spheres.column<4>()[i]), cr.push_back(spheres.column<5>()[i]), cm.push_back(spheres.column<1>()[i]);
+	for (size_t i = 0; i < planes.size(); i++)
+		pnx.push_back(planes.column<2>()[i]), pny.push_back(planes.column<3>()[i]), pnz.push_back(planes.column<4>()[i]), pd.push_back(planes.column<5>()[i]), pm.push_back(planes.column<1>()[i]);
+	for (size_t i = 0; i < materials.size(); i++)
+	{
+		const colour_value c = materials.column<2>()[i];
+		albedo.insert(albedo.end(), { c.r, c.g, c.b, c.a });
+		rough.push_back(materials.column<3>()[i]), refl.push_back(materials.column<4>()[i]), mt.push_back(materials.column<1>()[i]);
+	}
+	rt_hip_scene packed = s;
+	packed.sphere_center_x = cx.data(), packed.sphere_center_y = cy.data(), packed.sphere_center_z = cz.data(), packed.sphere_radius = cr.data(), packed.sphere_material = cm.data();
+	packed.plane_normal_x = pnx.data(), packed.plane_normal_y = pny.data(), packed.plane_normal_z = pnz.data(), packed.plane_d = pd.data(), packed.plane_material = pm.data();
+	packed.material_type = mt.data(), packed.material_albedo = albedo.data(), packed.material_roughness = rough.data(), packed.material_reflectivity = refl.data();
+	uint64_t print_packed = 0;
+	EXPECT(rt_hip_scene_check(&packed, &print_packed) == RT_HIP_OK);
+	EXPECT(print_packed == print_clean); // the fingerprint is of the rows, not of where they live
+	const frame from_vectors = render(packed, width, height);
+	EXPECT(from_vectors.rgba == clean.rgba && from_vectors.stats.segments == clean.stats.segments);
+
+	// a real out-of-range index INSIDE size() is still refused, and a changed row moves the fingerprint
+	spheres.column<1>()[3] = 99u;
+	EXPECT(rt_hip_scene_check(&s, nullptr) == RT_HIP_INVALID_ARGUMENT);
+	spheres.column<1>()[3] = 3u;
+	spheres.column<5>()[10] += 0.125f;
+	uint64_t print_edited = 0;
+	EXPECT(rt_hip_scene_check(&s, &print_edited) == RT_HIP_OK && print_edited != print_clean);
+
+	std::printf("%s: %zu spheres in capacity %zu, %zu planes in capacity %zu, %zu materials in capacity %zu; %llu segments; fingerprint %016llx\n", failures ? "FAILED" : "OK",
+				spheres.size(), spheres.capacity(), planes.size(), planes.capacity(), materials.size(), materials.capacity(), static_cast<unsigned long long>(clean.stats.segments),
+				static_cast<unsigned long long>(print_clean));
+	return failures ? 1 : 0;
+}

@@ -48,6 +48,9 @@ def test_single_gpu_line_has_the_contract_keys_roofline_and_cpu_baseline():
     assert line["drop_in_breakdown"]["wall_ms"] == pytest.approx(line["ms_per_step"])
     assert line["drop_in_breakdown"]["kernel_ms"] <= line["ms_per_step"]
     assert line["kernel_only"]["value"] >= 0.95 * line["value"]
+    # the call as the plug-in makes it (stats == NULL) is never slower than the timed one, which keeps the events
+    assert line["plug_in_call"]["ms_per_step"] <= line["ms_per_step"] * 1.02
+    assert {"render_ms", "host_issue_ms", "host_wait_ms"} <= set(line["drop_in_breakdown"])
     assert "scenes/basic.toml" in line["data"]
     assert "EPYC" in cpu["sample"] or "CPU" in cpu["sample"] or "Xeon" in cpu["sample"]
 
@@ -59,6 +62,21 @@ def test_one_process_drives_several_members_through_the_c_abi():
     line = run_bench(["--gpus", "4", "--same-device", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0"])
     assert line["n_gpus"] == 4 and "ONE process" in line["config"]["parallelism"] and "cpu_baseline" not in line
     assert line["value"] == pytest.approx(1920 * 1080 * 16 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    # what makes the first real multi-GPU run readable: who took part, every member's own kernel time, and
+    # where the root's time went
+    assert line["rccl"]["ranks"] == 4 and line["rccl"]["devices"] == [0, 0, 0, 0] and line["rccl"]["transport"] == "peer_copy"
+    per_rank = line["per_rank"]
+    assert len(per_rank["kernel_ms"]) == 4 and 0 < per_rank["kernel_ms_min"] <= per_rank["kernel_ms_max"] < line["ms_per_step"]
+    split = line["drop_in_breakdown"]
+    assert {"render_ms", "gather_ms", "assemble_ms", "copy_ms", "host_issue_ms", "host_wait_ms", "wall_ms"} <= set(split)
+    assert split["render_ms"] > 0 and split["assemble_ms"] > 0 and split["copy_ms"] >= 0
+    assert split["render_ms"] + split["gather_ms"] + split["assemble_ms"] + split["copy_ms"] <= split["wall_ms"] * 1.05
+
+
+@pytest.mark.gpu
+def test_direct_frame_line_says_that_nothing_was_exchanged():
+    line = run_bench(["--gpus", "2", "--same-device", "--direct-frame", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0"])
+    assert line["rccl"]["transport"] == "direct_frame" and line["drop_in_breakdown"]["assemble_ms"] == 0
 
 
 @pytest.mark.gpu
@@ -74,6 +92,8 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_step():
     line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
     assert "one process per GPU" in line["config"]["parallelism"] and line["config"]["frames_in_flight"] == 1
+    assert line["value_from"] == "torch" and "gloo" in line["paths"]["library"]["status"]
+    assert len(line["per_rank"]["kernel_ms"]) == 2 and line["paths"]["torch"]["ms_per_step"] == pytest.approx(line["ms_per_step"])
 
 
 @pytest.mark.gpu
@@ -90,3 +110,31 @@ def test_one_rank_under_torchrun_takes_the_library_rank_path():
     assert line["n_gpus"] == 1 and "ncclCommInitRank" in line["config"]["parallelism"]
     assert line["value"] == pytest.approx(1920 * 1080 * 32 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert 0 < line["roofline"]["frac"] < 1
+    # both forms ran; the library form came up, reproduced the torch form's frame and is what `value` reports
+    assert line["value_from"] == "library" and line["paths"]["library"]["status"] == "ok" and line["paths"]["torch"]["value"] > 0
+    assert line["paths"]["library"]["ms_per_step"] == pytest.approx(line["ms_per_step"])
+    # what RCCL itself says about the communicator, every rank's kernel time, the root's split of a step
+    assert line["rccl"] == {"ranks": 1, "devices": [0], "rank_of_process": [0], "transport": "rccl_gather", "source": line["rccl"]["source"]}
+    assert len(line["per_rank"]["kernel_ms"]) == 1 and 0 < line["per_rank"]["kernel_ms_max"] <= line["ms_per_step"]
+    split = line["drop_in_breakdown"]
+    assert {"render_ms", "gather_ms", "assemble_ms", "copy_ms", "host_issue_ms", "host_wait_ms", "wall_ms"} <= set(split)
+    assert split["render_ms"] > 0 and split["wall_ms"] == pytest.approx(line["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_a_library_form_that_hangs_still_yields_the_torch_line():
+    """The watchdog of the N > 1 flow: if the module's own renderer never finishes (RT_BENCH_TEST_HANG stalls the library
+    form in this test), the benchmark prints the torch form's line — marked as such — and ends, instead of losing the run."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    os.environ["RT_BENCH_TEST_HANG"] = "1"
+    try:
+        line = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0", "--library-deadline-s", "5"], launcher=launcher)
+    finally:
+        del os.environ["RT_BENCH_TEST_HANG"]
+    assert line["value_from"] == "torch" and "hung" in line["paths"]["library"]["status"]
+    assert line["value"] == pytest.approx(1920 * 1080 * 16 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)

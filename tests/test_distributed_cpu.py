@@ -72,3 +72,74 @@ def test_assemble_refuses_device_buffers_without_a_tracer():
 
     with pytest.raises(rt_amd.RtHipError):
         distributed.assemble(FakeCuda(), 8, 16, 8, tracer=None)
+
+
+# ---- bringing up the module's own multi-GPU renderer: vote first, then the collective call ------------------------------------
+
+
+class _FakeTracer:
+    def __init__(self):
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+def _negotiate_worker(rank, world, port, fail_stage, fail_rank, out_dir):
+    sys.path.insert(0, str(ROOT))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rt_amd import distributed
+
+        made, entered_join = [], []
+
+        def create():
+            if fail_stage == "create" and rank == fail_rank:
+                raise RuntimeError("rt_hip_create: no HIP device is visible")
+            made.append(_FakeTracer())
+            return made[-1]
+
+        def make_id():
+            if fail_stage == "id":
+                raise RuntimeError("ncclGetUniqueId failed")
+            return bytes(range(128))
+
+        def join(tracer, unique):
+            entered_join.append(unique)
+            assert unique == bytes(range(128))  # rank 0's id reached every rank unchanged
+            if fail_stage == "join" and rank == fail_rank:
+                raise RuntimeError("RT_HIP_TIMEOUT: waited 1500 ms in ncclCommInitRank")
+
+        tracer, why = distributed.negotiate_rank_renderer(create, join, make_id)
+        with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+            f.write(f"{int(tracer is not None)}|{len(entered_join)}|{int(all(t.closed for t in made) if made else 1)}|{why}")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize(
+    "fail_stage,fail_rank,world",
+    [("none", 0, 2), ("create", 1, 2), ("create", 0, 3), ("id", 0, 2), ("join", 1, 2), ("join", 2, 3)],
+)
+@pytest.mark.timeout(120)
+def test_a_rank_that_cannot_come_up_makes_every_rank_fall_back_and_nobody_hangs(tmp_path, fail_stage, fail_rank, world):
+    """VERDICT r2 / ADVICE r2: rt_hip_create_rank is collective; a rank that failed in front of ncclCommInitRank used to leave
+    the others waiting in it.  Now: the local half first, a vote, and only then the collective half — so a rank whose
+    context cannot be created keeps EVERY rank out of the collective call, and a failure inside it (it has a deadline of its
+    own) is voted on again.  All ranks agree on the outcome, contexts made in vain are closed, and the test ends: no hang."""
+    mp.spawn(_negotiate_worker, args=(world, _free_port(), fail_stage, fail_rank, str(tmp_path)), nprocs=world, join=True)
+    outcomes = [open(tmp_path / f"rank{r}.txt").read().split("|") for r in range(world)]
+    got_tracer = [o[0] for o in outcomes]
+    assert len(set(got_tracer)) == 1, outcomes  # every rank reached the same verdict
+    if fail_stage == "none":
+        assert got_tracer[0] == "1" and all(o[1] == "1" for o in outcomes)
+        return
+    assert got_tracer[0] == "0"
+    assert all(o[2] == "1" for o in outcomes)  # whatever was created has been closed again
+    entered = [o[1] for o in outcomes]
+    if fail_stage in ("create", "id"):
+        assert entered == ["0"] * world, outcomes  # NOBODY entered the collective call
+    assert all(o[3] != "None" for o in outcomes)  # and everybody can say why

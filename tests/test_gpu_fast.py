@@ -8,12 +8,14 @@ parity contract's, so a FAST frame differs from the exact frame only by
   (b) the rare sample whose hit/miss (or closest-sphere) decision flips at a silhouette: its whole contribution changes,
       which moves that pixel's mean by up to 1/spp of the sample's value.
 The bounds below are the tolerance, measured with tools/gpu_fast_probe.py (profiles/r02/fast_vs_exact.txt) and set with
-about 3x margin.  The reference frame is the exact GPU frame, which the parity tests hold to the oracle at 0 ulp.
+about 3x margin.  The reference is the ORACLE's frame — packed pixels, float32 mean and segment count of a 1/8 (1/16 at
+4K) sample of the frame's stripes — not another GPU frame.
 """
 import numpy as np
 import pytest
 
 import rt_amd
+from oracle import binding as oracle
 from rt_amd import capi
 
 pytestmark = pytest.mark.gpu
@@ -21,23 +23,42 @@ pytestmark = pytest.mark.gpu
 FAST = capi.RT_HIP_FLAG_FAST
 
 
-def compare(tracer, name, width, height, spp, seed=1):
+def compare(tracer, name, width, height, spp, seed=1, oracle_world=8, oracle_rank=3):
+    """FAST against the ORACLE (not against the exact GPU frame): the oracle renders every `oracle_world`-th
+    stripe of the frame — a 1/oracle_world sample of its rows, spread over the whole height — and the FAST kernel renders
+    the same partition; packed pixels, float means and segment counts of that share are compared.  Only the speed-up is
+    GPU against GPU (two whole-frame launches)."""
+    import torch
+
     pod = rt_amd.Scene.named(name).set_sampling(spp).describe(width, height)
-    exact8, exact, exact_stats = tracer.render(pod, width, height, seed=seed, want_rgb=True)
-    fast8, fast, fast_stats = tracer.render(pod, width, height, seed=seed, flags=FAST, want_rgb=True)
+    part = (oracle_rank % oracle_world, oracle_world, capi.RT_HIP_DEFAULT_STRIPE_ROWS)
+    exact8, exact, exact_stats = oracle.render(pod, width, height, seed=seed, partition=part)
+    rows = exact8.shape[0]
+    padded = rt_amd.padded_local_rows(height, oracle_world)
+    d_rgba = torch.zeros((padded, width), dtype=torch.int32, device="cuda:0")
+    d_rgb = torch.zeros((padded, width, 3), dtype=torch.float32, device="cuda:0")
+    tracer.upload(pod)
+    tracer.render_device(width, height, d_rgba.data_ptr(), seed=seed, flags=FAST, partition=part, d_rgb_f32=d_rgb.data_ptr(), stream=torch.cuda.current_stream().cuda_stream)
+    fast_stats = tracer.stats()
+    fast8 = d_rgba.cpu().numpy().view(np.uint32)[:rows]
+    fast = d_rgb.cpu().numpy()[:rows]
     assert np.isfinite(fast).all() and (fast >= 0).all() and np.all((fast8 & 0xFF) == 0xFF)
     rel = np.abs(exact - fast).max(axis=2) / np.maximum(np.abs(exact).max(axis=2), 1e-6)
     channels = lambda a: np.stack([(a >> s) & 255 for s in (24, 16, 8)], -1).astype(int)
     lsb = np.abs(channels(exact8) - channels(fast8)).max(axis=2)
+    # speed: the whole frame, exact and FAST kernels
+    _, _, whole_exact = tracer.render(pod, width, height, seed=seed)
+    _, _, whole_fast = tracer.render(pod, width, height, seed=seed, flags=FAST)
     return {
         "within_2e-5": float((rel <= 2e-5).mean()),
         "beyond_1e-3": float((rel > 1e-3).mean()),
         "median": float(np.median(rel)),
         "rgba8_within_1": float((lsb <= 1).mean()),
         "segments": abs(fast_stats["segments"] - exact_stats["segments"]) / exact_stats["segments"],
-        "mean": float(np.abs(fast.mean(axis=(0, 1)) / exact.mean(axis=(0, 1)) - 1).max()),
-        "speedup": exact_stats["render_ms"] / fast_stats["render_ms"],
+        "mean": float(np.abs(fast.astype(np.float64).mean(axis=(0, 1)) / exact.astype(np.float64).mean(axis=(0, 1)) - 1).max()),
+        "speedup": whole_exact["render_ms"] / whole_fast["render_ms"],
         "kernel": fast_stats["kernel"],
+        "pixels_compared": int(rel.size),
     }
 
 
@@ -51,20 +72,20 @@ def compare(tracer, name, width, height, spp, seed=1):
     ],
 )
 def test_fast_frames_of_the_baseline_scenes_stay_within_the_stated_tolerance(tracer, name, width, height, spp):
-    r = compare(tracer, name, width, height, spp)
+    r = compare(tracer, name, width, height, spp, oracle_world=16 if width > 1920 else 8)
     print(name, width, height, spp, r)
-    assert r["kernel"] == "small"
+    assert r["kernel"] == "small" and r["pixels_compared"] >= width * height // 17
     assert r["within_2e-5"] >= 0.99  # measured 0.9952 .. 0.9984: everything but the pixels with a flipped sample
     assert r["beyond_1e-3"] <= 0.006  # measured <= 0.0021: the flipped ones
     assert r["median"] <= 1e-7  # more than half of all pixels are bit-identical (measured 0)
     assert r["rgba8_within_1"] >= 0.9997  # measured >= 0.99993
-    assert r["segments"] <= 5e-6  # measured <= 7e-7: flips are rare and go both ways
+    assert r["segments"] <= 2e-5  # measured <= 7e-7 on whole frames: flips are rare and go both ways (a 1/8 share here)
     assert r["mean"] <= 1e-5  # the image as a whole does not move
     assert r["speedup"] > 1.03  # it is there to be faster (measured 1.20 .. 1.30)
 
 
 def test_fast_config1_size(tracer):
-    r = compare(tracer, "basic", 256, 256, 1)
+    r = compare(tracer, "basic", 256, 256, 1, oracle_world=1, oracle_rank=0)
     print(r)
     assert r["within_2e-5"] >= 0.98 and r["rgba8_within_1"] >= 0.9995 and r["mean"] <= 1e-4
 
@@ -74,7 +95,7 @@ def test_fast_on_the_sphere_field_is_the_same_picture_statistically(tracer):
     of the pixels holds a flipped sample; what must hold is that the picture is the same estimate — frame mean, path
     statistics — and that most packed pixels still agree.  (FAST buys nothing here: the scan is 12 instructions per test
     either way; 1.01x at full size.)"""
-    r = compare(tracer, "synthetic-100k", 480, 270, 64)
+    r = compare(tracer, "synthetic-100k", 480, 270, 64, oracle_world=17)  # two stripes of the field: 1.9e10 sphere tests on the host
     print(r)
     assert r["kernel"] == "streamed"
     assert r["mean"] <= 5e-3  # measured 1.4e-3 at full size
@@ -93,7 +114,7 @@ def test_fast_is_refused_for_the_other_renderers(tracer):
 
 def test_fast_goes_through_every_kernel_mode_and_the_multi_gpu_context(tracer):
     pod = rt_amd.Scene.named("basic").set_sampling(8).describe(200, 120)
-    exact, _, _ = tracer.render(pod, 200, 120, seed=3)
+    exact, _, _ = oracle.render(pod, 200, 120, seed=3, want_rgb=False)
     for flags, kernel in [(0, "small"), (capi.RT_HIP_FLAG_FORCE_RESIDENT, "resident"), (capi.RT_HIP_FLAG_FORCE_TILED, "tiled"), (capi.RT_HIP_FLAG_FORCE_STREAMED, "streamed")]:
         fast, _, stats = tracer.render(pod, 200, 120, seed=3, flags=FAST | flags)
         assert stats["kernel"] == kernel

@@ -1,0 +1,343 @@
+"""The host side of rt_hip_render around the launch: what is enqueued, what is remembered, what survives a caller that
+re-creates its buffers.
+
+The reference's render() is one blocking call that gets a scene and a back buffer it knows nothing else about
+(reference src/renderer.hpp:9-14); rt re-renders after every edit (src/main.cpp:233-311), re-creates its images on resize
+(src/window.cpp:198-203, src/image.cpp:9-34) and shows low-resolution frames while the camera moves (src/main.cpp:315-321),
+where the launch, not the kernel, is what a frame costs.  Every frame here is compared with the oracle's bit for bit.
+"""
+import ctypes as C
+import mmap
+import subprocess
+import sys
+import textwrap
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+import rt_amd
+from oracle import binding as oracle
+from rt_amd import capi
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _scene(name, spp, bounces=10):
+    return rt_amd.Scene.named(name).set_sampling(spp, bounces)
+
+
+# ---- the plug-in's call: stats == NULL -----------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("name,flags", [("basic", 0), ("basic", capi.RT_HIP_FLAG_FORCE_RESIDENT), ("synthetic-1500", capi.RT_HIP_FLAG_FORCE_TILED), ("synthetic-1500", capi.RT_HIP_FLAG_FORCE_STREAMED)])
+def test_frames_without_stats_are_the_same_frames(tracer, name, flags):
+    """stats == NULL enqueues nothing but the launch (no events, no counter traffic): same pixels, for every kernel mode —
+    the big-scene kernels still need their tile queue's head reset — whether the buffer is page-locked or not, several
+    frames in a row, interleaved with frames that do keep stats."""
+    width, height, spp = 160, 90, 4
+    pod = _scene(name, spp).describe(width, height)
+    want = {seed: oracle.render(pod, width, height, seed=seed, want_rgb=False) for seed in (3, 4)}
+    back = np.zeros((height, width), dtype=np.uint32)
+    for persistent in (0, capi.RT_HIP_FLAG_PERSISTENT_FRAME):
+        for seed, keep in [(3, False), (4, False), (3, True), (4, False), (3, False)]:
+            back[:] = 0
+            _, _, stats = tracer.render(pod, width, height, seed=seed, flags=flags | persistent, out=back, stats=keep)
+            assert np.array_equal(back, want[seed][0]), (persistent, seed, keep)
+            if keep:
+                assert stats["segments"] == want[seed][2]["segments"] and stats["render_ms"] > 0
+            else:
+                assert stats == {}
+                later = tracer.stats()  # nothing stale: the frame's counters were not kept
+                assert later["segments"] == 0 and later["render_ms"] == 0 and later["primary_samples"] == width * height * spp
+    tracer.forget_frame()
+
+
+def test_stats_flag_keeps_the_counters_without_a_stats_pointer(tracer):
+    width, height = 96, 54
+    pod = _scene("basic", 3).describe(width, height)
+    _, _, want = oracle.render(pod, width, height, seed=8, want_rgb=False)
+    for _ in range(2):  # (the second frame finds the columns resident)
+        tracer.render(pod, width, height, seed=8, flags=capi.RT_HIP_FLAG_STATS, stats=False)
+    later = tracer.stats()
+    assert later["segments"] == want["segments"] and later["render_ms"] > 0
+    phases = tracer.phases()
+    assert phases["transport"] == "none" and phases["render_ms"] > 0 and phases["gather_ms"] == 0 and phases["scene_resident"] == 1
+    assert phases["host_issue_ms"] > 0 and phases["host_wait_ms"] >= 0
+    assert tracer.comm_info() == {"ranks": 1, "rank": 0, "device": 0, "transport": "none"}
+
+
+# ---- the scene fingerprint is taken over the caller's columns, where they lie ----------------------------------------------
+
+
+def test_columns_edited_in_place_are_noticed(tracer):
+    """rt has no scene version counter (reference src/main.cpp:233-311): the module fingerprints the caller's columns on
+    every call.  Same pointers, one float changed -> re-uploaded; changed back -> the first frame again."""
+    width, height, seed = 120, 68, 2
+    scene = _scene("basic", 3)
+    pod = scene.describe(width, height)
+    first, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    got, _, _ = tracer.render(pod, width, height, seed=seed)
+    assert np.array_equal(got, first) and tracer.phases()["scene_resident"] in (0, 1)
+    got, _, _ = tracer.render(pod, width, height, seed=seed)
+    assert np.array_equal(got, first) and tracer.phases()["scene_resident"] == 1
+    radius = np.ctypeslib.as_array(pod.sphere_radius, shape=(pod.n_spheres,))
+    albedo = np.ctypeslib.as_array(pod.material_albedo, shape=(pod.n_materials * 4,))
+    kept = (radius[1], albedo[5])
+    radius[1] *= 1.5
+    edited, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    assert not np.array_equal(edited, first)
+    got, _, _ = tracer.render(pod, width, height, seed=seed)
+    assert np.array_equal(got, edited) and tracer.phases()["scene_resident"] == 0
+    albedo[5] = 0.25  # a material column this time
+    edited, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    got, _, _ = tracer.render(pod, width, height, seed=seed)
+    assert np.array_equal(got, edited) and tracer.phases()["scene_resident"] == 0
+    radius[1], albedo[5] = kept
+    got, _, _ = tracer.render(pod, width, height, seed=seed)
+    assert np.array_equal(got, first)
+
+
+def test_a_bad_material_index_is_still_refused_and_does_not_poison_the_resident_scene(tracer):
+    width, height = 64, 36
+    good = _scene("basic", 2).describe(width, height)
+    want, _, _ = oracle.render(good, width, height, seed=1, want_rgb=False)
+    tracer.render(good, width, height, seed=1)
+    bad = rt_amd.scene_from_arrays(spheres=[(0, 0, -5, 1, 3)], materials=[(0, 1, 1, 1, 1, 0.5, 0.5)])
+    for _ in range(2):  # (a second time: the refusal must not have been remembered as "seen")
+        with pytest.raises(rt_amd.RtHipError, match="out-of-range"):
+            tracer.render(bad, width, height)
+    got, _, _ = tracer.render(good, width, height, seed=1)
+    assert np.array_equal(got, want)
+
+
+# ---- one context, two streams -----------------------------------------------------------------------------------------------
+
+
+def test_launches_on_two_streams_of_one_context_do_not_race():
+    """A context's launches share the work counters and the tile queue's head: moving to another stream waits for the old
+    one.  Big-scene kernel (it pulls pixel tiles from the shared queue), alternating streams, no host sync in
+    between."""
+    import torch
+
+    width, height, spp = 128, 72, 4
+    pod = _scene("synthetic-1500", spp).describe(width, height)
+    want = {seed: oracle.render(pod, width, height, seed=seed, want_rgb=False) for seed in (1, 2)}
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    frames = [torch.zeros((height, width), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    with rt_amd.HipRayTracer(device=0) as mine:
+        mine.upload(pod)
+        for i in range(6):
+            k = i % 2
+            mine.render_device(width, height, frames[k].data_ptr(), seed=1 + k, flags=capi.RT_HIP_FLAG_FORCE_TILED, stream=streams[k].cuda_stream)
+        stats = mine.stats()
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert np.array_equal(frames[k].cpu().numpy().view(np.uint32), want[1 + k][0])
+        assert stats["segments"] == want[2][2]["segments"]  # of the last launch (stream 1)
+        # rt_hip_render on the context's own stream right behind a launch on a caller's stream
+        mine.render_device(width, height, frames[0].data_ptr(), seed=2, flags=capi.RT_HIP_FLAG_FORCE_TILED, stream=streams[0].cuda_stream)
+        got, _, _ = mine.render(pod, width, height, seed=1, flags=capi.RT_HIP_FLAG_FORCE_TILED)
+        assert np.array_equal(got, want[1][0])
+        torch.cuda.synchronize()
+        assert np.array_equal(frames[0].cpu().numpy().view(np.uint32), want[2][0])
+
+
+# ---- the caller re-creates its back buffer ------------------------------------------------------------------------------------
+
+
+def _map_at(address, size):
+    """An anonymous private mapping of `size` bytes; at `address` if given (MAP_FIXED_NOREPLACE: never on top of anything)."""
+    libc = C.CDLL(None, use_errno=True)
+    libc.mmap.restype = C.c_void_p
+    libc.mmap.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_long]
+    map_fixed_noreplace = 0x100000
+    flags = mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS | (map_fixed_noreplace if address else 0)
+    got = libc.mmap(address, size, mmap.PROT_READ | mmap.PROT_WRITE, flags, -1, 0)
+    assert got not in (None, C.c_void_p(-1).value), f"mmap failed: errno {C.get_errno()}"
+    return got
+
+
+def _unmap(address, size):
+    libc = C.CDLL(None, use_errno=True)
+    libc.munmap.argtypes = [C.c_void_p, C.c_size_t]
+    assert libc.munmap(address, size) == 0
+
+
+@pytest.mark.parametrize("members", [1, 2])
+def test_back_buffer_unmapped_and_mapped_again_at_the_same_address(members):
+    """rt re-creates its images on resize (reference src/window.cpp:198-203, src/image.cpp:9-34); an allocator may hand the
+    new image the old address.  The page-lock taken under RT_HIP_FLAG_PERSISTENT_FRAME follows the ADDRESS RANGE, and the
+    range's pages went back to the kernel with the old mapping.  rt_hip_forget_frame between the two mappings makes the
+    sequence clean, which is what this test holds the module to.
+
+    The same sequence WITHOUT rt_hip_forget_frame was run on this pool exactly once, on purpose
+    (profiles/r03/remap_without_forget.txt): the registration does not follow the new mapping — the next frame's first
+    store into it is a GPU memory access fault and the process is aborted by the HSA runtime.  It is not repeated here (a
+    faulting kernel can take a shared node down); INTEGRATION.md §3 says what a caller must do instead."""
+    width, height, seed = 256, 144, 6
+    size = width * height * 4  # 36 whole pages
+    pod = _scene("basic", 3).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    kwargs = {"device": 0} if members == 1 else {"devices": [0] * members, "peer_copy": True}
+    with rt_amd.HipRayTracer(**kwargs) as mine:
+        address = _map_at(None, size)
+        view = np.ctypeslib.as_array((C.c_uint32 * (width * height)).from_address(address)).reshape(height, width)
+        for _ in range(2):
+            view[:] = 0
+            mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=view, stats=False)
+            assert np.array_equal(view, want)
+        del view
+        mine.forget_frame()
+        _unmap(address, size)
+        again = _map_at(address, size)
+        assert again == address
+        view = np.ctypeslib.as_array((C.c_uint32 * (width * height)).from_address(address)).reshape(height, width)
+        assert not view.any()  # fresh zero pages
+        for _ in range(2):
+            view[:] = 0
+            mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=view, stats=False)
+            assert np.array_equal(view, want)
+        del view
+        mine.forget_frame()
+        _unmap(address, size)
+
+
+def test_a_freed_back_buffer_of_another_size_is_simply_replaced():
+    """The ordinary resize: the old image is freed, the new one has another size (and possibly an overlapping address).  The
+    module drops the old page-lock — on memory that is already gone: hipHostUnregister may fail, which must not leak into
+    the next call — and locks the new buffer."""
+    seed = 6
+    with rt_amd.HipRayTracer(device=0) as mine:
+        for width, height in [(256, 144), (128, 72), (256, 144), (320, 180)]:
+            pod = _scene("basic", 2).describe(width, height)
+            want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+            size = width * height * 4
+            address = _map_at(None, size)
+            view = np.ctypeslib.as_array((C.c_uint32 * (width * height)).from_address(address)).reshape(height, width)
+            mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=view, stats=False)
+            assert np.array_equal(view, want)
+            del view
+            _unmap(address, size)  # freed while still page-locked; the next frame arrives with another size
+
+
+def test_unaligned_back_buffer_is_locked_without_touching_its_neighbours():
+    """The NUMA move is applied to the pages that lie wholly inside the buffer: a frame that starts and ends in the middle of
+    pages (rt's images are 64-byte aligned, src/image.hpp:11) leaves the bytes around it alone and still arrives."""
+    width, height, seed = 200, 117, 4
+    pod = _scene("basic", 2).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    arena = np.full(width * height + 4096, 0xA5A5A5A5, dtype=np.uint32)
+    offset = 16 + (-(arena.ctypes.data // 4) % 16)  # 64-byte aligned, not page aligned
+    if (arena.ctypes.data + 4 * offset) % 4096 == 0:
+        offset += 16
+    view = arena[offset : offset + width * height].reshape(height, width)
+    assert view.ctypes.data % 4096 != 0 and view.ctypes.data % 64 == 0
+    with rt_amd.HipRayTracer(device=0) as mine:
+        for _ in range(2):
+            mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=view, stats=False)
+            assert np.array_equal(view, want)
+    assert (arena[:offset] == 0xA5A5A5A5).all() and (arena[offset + width * height :] == 0xA5A5A5A5).all()
+
+
+# ---- several members: what the exchange reports -------------------------------------------------------------------------------
+
+
+@pytest.mark.parametrize("members", [2, 4])
+def test_phases_and_comm_info_of_a_multi_member_frame(members):
+    width, height, spp, seed = 320, 180, 8, 5
+    pod = _scene("basic", spp).describe(width, height)
+    want, _, want_stats = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    back = np.zeros((height, width), dtype=np.uint32)
+    with rt_amd.HipRayTracer(devices=[0] * members, peer_copy=True) as mine:
+        for r in range(members):
+            assert mine.comm_info(r) == {"ranks": members, "rank": r, "device": 0, "transport": "peer_copy"}
+        # pageable buffer: stripes of every member gathered, assembled in HBM, one copy
+        got, _, stats = mine.render(pod, width, height, seed=seed)
+        phases = mine.phases()
+        assert np.array_equal(got, want) and stats["segments"] == want_stats["segments"]
+        assert phases["transport"] == "peer_copy" and phases["render_ms"] > 0 and phases["assemble_ms"] > 0 and phases["copy_ms"] > 0
+        # page-locked buffer: the root's stripes go straight to the frame, the others are assembled into it — no copy
+        for _ in range(2):
+            back[:] = 0
+            _, _, stats = mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back)
+            phases = mine.phases()
+            assert np.array_equal(back, want) and stats["segments"] == want_stats["segments"]
+            assert phases["assemble_ms"] > 0 and phases["gather_ms"] >= 0
+        assert phases["scene_resident"] == 1
+        # the same without stats: nothing but launches, copies and the assemble kernel
+        back[:] = 0
+        mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back, stats=False)
+        assert np.array_equal(back, want)
+        assert mine.phases()["render_ms"] == 0 and mine.stats()["segments"] == 0
+
+
+def test_direct_frame_reports_its_transport():
+    width, height, seed = 192, 108, 2
+    pod = _scene("basic", 4).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    back = np.zeros((height, width), dtype=np.uint32)
+    with rt_amd.HipRayTracer(devices=[0, 0, 0], peer_copy=True, direct_frame=True) as mine:
+        assert mine.comm_info()["transport"] == "peer_copy"  # nothing rendered yet
+        for keep in (True, False):
+            back[:] = 0
+            mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back, stats=keep)
+            assert np.array_equal(back, want)
+            assert mine.phases()["transport"] == "direct_frame" and mine.comm_info(1)["transport"] == "direct_frame"
+        got, _, _ = mine.render(pod, width, height, seed=seed)  # a pageable buffer falls back to the gathered way
+        assert np.array_equal(got, want) and mine.phases()["transport"] == "peer_copy"
+
+
+# ---- one process per GPU: the two halves of rt_hip_create_rank -------------------------------------------------------------------
+
+
+def test_join_ranks_after_a_plain_create_and_what_rccl_reports():
+    width, height, seed = 160, 90, 3
+    pod = _scene("basic", 4).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    with rt_amd.HipRayTracer(device=0) as mine:  # the half that can fail alone
+        got, _, _ = mine.render(pod, width, height, seed=seed)
+        assert np.array_equal(got, want)
+        mine.join_ranks(0, 1, rt_amd.unique_id(), timeout_ms=60000)  # the collective half (a world of one)
+        assert mine.comm_info() == {"ranks": 1, "rank": 0, "device": 0, "transport": "rccl_gather"}
+        back = np.zeros((height, width), dtype=np.uint32)
+        for flags in (0, capi.RT_HIP_FLAG_PERSISTENT_FRAME):
+            back[:] = 0
+            mine.render(pod, width, height, seed=seed, flags=flags, out=back)
+            assert np.array_equal(back, want)
+            assert mine.phases()["transport"] == "rccl_gather"
+        with pytest.raises(rt_amd.RtHipError, match="already belongs"):
+            mine.join_ranks(0, 1, rt_amd.unique_id())
+
+
+def test_join_ranks_gives_up_after_its_deadline():
+    """A rank that waits for ranks that never come (they died between the launcher's vote and the collective call) gets
+    RT_HIP_TIMEOUT instead of hanging, and still holds a working single-GPU context.  In a child process that leaves with
+    os._exit: the helper thread is still inside ncclCommInitRank, and a normal interpreter shutdown would wait on RCCL."""
+    code = textwrap.dedent(
+        """
+        import os, sys, time
+        sys.path.insert(0, %r)
+        import numpy as np
+        import rt_amd
+        from oracle import binding as oracle
+        pod = rt_amd.Scene.named("basic").set_sampling(2).describe(64, 36)
+        want, _, _ = oracle.render(pod, 64, 36, seed=1, want_rgb=False)
+        t = rt_amd.HipRayTracer(device=0)
+        t0 = time.perf_counter()
+        try:
+            t.join_ranks(0, 2, rt_amd.unique_id(), timeout_ms=1500)
+            print("JOINED")
+        except rt_amd.RtHipError as e:
+            print("status", e.status, "after %%.1f s" %% (time.perf_counter() - t0), str(e)[:120])
+        got, _, _ = t.render(pod, 64, 36, seed=1)
+        print("FRAME_OK" if np.array_equal(got, want) else "FRAME_BAD", t.comm_info())
+        sys.stdout.flush()
+        os._exit(0)
+        """
+        % str(ROOT)
+    )
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "status 6" in out.stdout and "FRAME_OK" in out.stdout, out.stdout + out.stderr
+    assert "'transport': 'none'" in out.stdout

@@ -482,3 +482,71 @@ def test_sm_material_mode_only_changes_refracting_materials():
     a, _, _ = oracle.render(pod, 64, 36, seed=9)
     b, b_rgb, _ = oracle.render(pod, 64, 36, seed=9, sm_materials=True)
     assert not np.array_equal(a, b) and np.isfinite(b_rgb).all()
+
+
+# ---- contract v3: normalize()'s reciprocal square root ------------------------------------------------------------------
+
+
+def _every_significand(first_bits: int) -> np.ndarray:
+    """All 2^24 floats of the two binades starting at the float with bit pattern `first_bits`."""
+    return (np.uint32(first_bits) + np.arange(1 << 24, dtype=np.uint32)).view(np.float32)
+
+
+@pytest.mark.parametrize("first_bits", [0x3F800000, 0x21800000, 0x5C800000], ids=["1..4", "2^-60..2^-58", "2^58..2^60"])
+def test_inv_sqrt_is_the_correctly_rounded_value_but_for_one_significand(first_bits):
+    """The contract's inv_sqrt (one Newton step from the truncated quotient) against 1/sqrt(x) evaluated in binary64 and
+    rounded to binary32, for EVERY significand at both exponent parities: equal everywhere except x = 4^k (1 - 2^-23),
+    where the step's first-order value is exactly a rounding midpoint and the result is 2^-k."""
+    x = _every_significand(first_bits)
+    got = oracle.inv_sqrt(x)
+    rounded = (1.0 / np.sqrt(x.astype(np.float64))).astype(np.float32)
+    differing = np.nonzero(got.view(np.uint32) != rounded.view(np.uint32))[0]
+    assert len(differing) == 1
+    bits = int(x.view(np.uint32)[differing[0]])
+    assert bits & 0x00FFFFFF == 0x007FFFFE  # odd biased exponent (x just below an even power of two), significand 1.11...10
+    k = ((bits >> 23) + 1 - 127) // 2  # x = 4^k (1 - 2^-23)
+    assert got[differing[0]] == np.float32(2.0) ** np.float32(-k)
+    assert rounded[differing[0]] == np.float32(2.0) ** np.float32(-k) * (np.float32(1) + np.float32(2.0**-23))
+    # and it is within 0.5000002 ulp even there
+    exact = 1.0 / np.sqrt(np.float64(x[differing[0]]))
+    assert abs(float(got[differing[0]]) - exact) <= 0.5000002 * float(np.spacing(got[differing[0]]))
+
+
+def test_inv_sqrt_step_barely_depends_on_the_estimate_it_starts_from():
+    """Why a hardware estimate can stand in for the truncated quotient — and why that has to be CHECKED on the hardware:
+    the step squares the estimate's error, so from any estimate within an ulp of the truth it gives the same binary32
+    result for all but a handful of the 2^24 significands (those whose exact value lies within ~2^-47 of a rounding
+    midpoint), and is within one ulp there.  rt_hip_kat_exhaustive_math establishes on the device under test that
+    v_rsq_f32's estimate gives the definition's result for EVERY input (tests/test_gpu_parity.py)."""
+    x = _every_significand(0x3F800000)
+    want = oracle.inv_sqrt(x)
+    nearest = (1.0 / np.sqrt(x.astype(np.float64))).astype(np.float32)
+    for offset in (-1, 0, 1):
+        estimate = (nearest.view(np.int32) + np.int32(offset)).view(np.float32)
+        got = oracle.inv_sqrt_step(x, estimate)
+        differing = np.nonzero(got.view(np.uint32) != want.view(np.uint32))[0]
+        assert len(differing) <= 8, (offset, len(differing))
+        assert np.all(np.abs(got.view(np.int32)[differing].astype(np.int64) - want.view(np.int32)[differing]) == 1)
+
+
+def test_inv_sqrt_outside_the_positive_normal_floats():
+    with np.errstate(all="ignore"):
+        x = np.array([0.0, -0.0, np.inf, -1.0, np.nan, 1e-45, 1.1754942e-38, 3.4028235e38, 1.1754944e-38], dtype=np.float32)
+        got = oracle.inv_sqrt(x)
+        plain = (1.0 / np.sqrt(x.astype(np.float64))).astype(np.float32)
+    assert got[0] == np.inf and got[1] == -np.inf and got[2] == 0.0 and np.isnan(got[3]) and np.isnan(got[4])
+    assert np.array_equal(got[5:7], plain[5:7])  # subnormal arguments: the plain quotient
+    assert np.array_equal(got[7:], plain[7:])  # largest and smallest normal: the step reproduces the rounded value
+
+
+def test_normalize_of_unit_vectors_stays_put():
+    """The case the contract change must not disturb: normalising an (almost) unit-length direction — metal_scatter does
+    it on every hit (mg_ray_tracer.cpp:133) — keeps every component within one ulp."""
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(200000, 3))
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype(np.float32)
+    d = (v[:, 0] * v[:, 0]).astype(np.float32)
+    d = (v[:, 1].astype(np.float64) * v[:, 1] + d).astype(np.float32)  # fma chain of the contract's dot()
+    d = (v[:, 2].astype(np.float64) * v[:, 2] + d).astype(np.float32)
+    scaled = v * oracle.inv_sqrt(d)[:, None]
+    assert np.max(np.abs(scaled.view(np.int32).astype(np.int64) - v.view(np.int32).astype(np.int64))) <= 1
