@@ -1351,9 +1351,11 @@ namespace
 			return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: a %ux%u frame over %u ranks exceeds the gather's element count", width, height, world);
 
 		// the caller's columns are looked at ONCE per frame, whatever the number of members: pointer check, fingerprint
+		const auto scene_t0 = std::chrono::steady_clock::now();
 		scene_request request;
 		if (const rt_hip_status st = open_request(request, scene))
 			return st;
+		const float fingerprint_ms = static_cast<float>(seconds_since(scene_t0) * 1e3); // (added to every member's upload_ms below)
 		root->phases = rt_hip_phases{};
 		root->phases.transport = root->peer_copy ? RT_HIP_TRANSPORT_PEER_COPY : RT_HIP_TRANSPORT_RCCL_GATHER;
 		settle_members settle(root);
@@ -1405,8 +1407,11 @@ namespace
 			{
 				root->phases.transport = RT_HIP_TRANSPORT_DIRECT_FRAME;
 				for (int r = 0; r < n; r++) // scenes first (normally: n fingerprint comparisons), then nothing but launches
+				{
 					if (const rt_hip_status st = make_resident(member_of(root, r), request))
 						return st;
+					member_of(root, r)->stats.upload_ms += fingerprint_ms;
+				}
 				settle.armed = true;
 				for (int r = 0; r < n; r++)
 				{
@@ -1443,6 +1448,7 @@ namespace
 			rt_hip_ctx* member = member_of(root, r);
 			if (const rt_hip_status st = make_resident(member, request))
 				return st;
+			member->stats.upload_ms += fingerprint_ms;
 			if (!(root_direct && r == 0))
 				RT_HIP_TRY(member->stripes_rgba.reserve(stripe_pixels * sizeof(uint32_t)));
 			if (rgb_f32)
@@ -1614,12 +1620,14 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		if (ctx->multi)
 			return render_multi(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats, entered);
 
+		const auto scene_t0 = std::chrono::steady_clock::now();
 		scene_request request;
 		if (const rt_hip_status st = open_request(request, scene))
 			return st;
 		ctx->phases = rt_hip_phases{};
 		if (const rt_hip_status st = make_resident(ctx, request))
 			return st;
+		ctx->stats.upload_ms = static_cast<float>(seconds_since(scene_t0) * 1e3); // the frame's whole scene check, fingerprint pass included
 		// A page-locked back buffer is mapped into the device's address space: the kernel stores every finished pixel
 		// straight into it (4 bytes per pixel over PCIe while the rest of the frame is still being traced), and
 		// there is no read-back step at all.  Otherwise the frame is rendered into HBM and copied.
@@ -1686,6 +1694,24 @@ extern "C" rt_hip_status rt_hip_debug_region_counters(rt_hip_ctx* ctx, uint64_t*
 		out[i] = ctx->counters_host->region_runs[i];
 		out[device_counters::regions + i] = ctx->counters_host->region_lanes[i];
 	}
+	return ok();
+}
+#endif
+
+#ifdef RT_HIP_WAVE_CLOCKS
+// experiment variant only: out[3 * w + {0, 1, 2}] = start / queue-dry / end tick (100 MHz) of wave w of the most recent
+// persistent launch on this context, for w < *count (in: capacity of `out` in waves; out: waves the build records)
+extern "C" rt_hip_status rt_hip_debug_wave_clocks(rt_hip_ctx* ctx, uint64_t* out, uint32_t* count)
+{
+	if (!ctx || !out || !count)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_debug_wave_clocks: NULL argument");
+	RT_HIP_TRY(hipSetDevice(ctx->device));
+	RT_HIP_TRY(hipEventSynchronize(ctx->counters_copied));
+	const uint32_t n = std::min<uint32_t>(*count, device_counters::clocked_waves);
+	for (uint32_t w = 0; w < n; w++)
+		for (int k = 0; k < 3; k++)
+			out[3 * w + k] = ctx->counters_host->wave_clocks[w][k];
+	*count = n;
 	return ok();
 }
 #endif

@@ -442,6 +442,10 @@ namespace rt_hip
 			uint32_t prefetched = 0;			 // the id the next opening will use: the atomic's latency is off the path
 			if (ROLLING)
 				prefetched = fetch_tile(counters);
+#ifdef RT_HIP_WAVE_CLOCKS
+			const unsigned long long clock_start = wall_clock64();
+			unsigned long long clock_dry = 0;
+#endif
 
 			lane_state st;
 			// path segments traced: counted on the scalar unit (one popcount of the tracing lanes per trip) where scalar
@@ -735,6 +739,9 @@ namespace rt_hip
 							if (prefetched >= total_tiles)
 							{
 								dry = true;
+#ifdef RT_HIP_WAVE_CLOCKS
+								clock_dry = wall_clock64();
+#endif
 								break;
 							}
 							cur ^= 1u;
@@ -916,6 +923,18 @@ namespace rt_hip
 					wave_segments += __shfl_down(wave_segments, offset, 64);
 			}
 			add_segments(counters, wave_segments);
+#ifdef RT_HIP_WAVE_CLOCKS
+			if (ROLLING && lane == 0)
+			{
+				const uint32_t id = blockIdx.x * 4u + wave;
+				if (id < device_counters::clocked_waves)
+				{
+					counters->wave_clocks[id][0] = clock_start;
+					counters->wave_clocks[id][1] = clock_dry;
+					counters->wave_clocks[id][2] = wall_clock64();
+				}
+			}
+#endif
 #ifdef RT_HIP_REGION_COUNTERS
 			if (lane == 0)
 				for (unsigned i = 0; i < device_counters::regions; i++)
@@ -1277,7 +1296,10 @@ namespace rt_hip
 			// one tile are then normally in before the next one is handed out; otherwise as small as possible (the queue
 			// balances the chip at tile granularity, and the slots of two tiles per wave live in LDS)
 			pixels_log2 = 0;
-			while (pixels_log2 < 7u && (q.chunks << pixels_log2) < 128u)
+#ifndef RT_HIP_BIG_TILE_ITEMS
+#define RT_HIP_BIG_TILE_ITEMS 128u
+#endif
+			while (pixels_log2 < 7u && (q.chunks << pixels_log2) < RT_HIP_BIG_TILE_ITEMS)
 				pixels_log2++;
 		}
 		else

@@ -109,6 +109,12 @@ namespace rt_hip
 		static constexpr unsigned regions = 13; // experiment variant only (kernels.hip, RT_HIP_REGION)
 		unsigned long long region_runs[regions], region_lanes[regions];
 #endif
+#ifdef RT_HIP_WAVE_CLOCKS
+		// experiment variant only (tools/gpu_wave_tail.py): when every wave of a persistent launch started, found the
+		// tile queue dry and retired, in ticks of the constant 100 MHz clock (s_memrealtime)
+		static constexpr unsigned clocked_waves = 16384;
+		unsigned long long wave_clocks[clocked_waves][3];
+#endif
 	};
 
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel

@@ -63,6 +63,20 @@ namespace
 		return rt_hip_create_multi(ctx, devices, n, flags); // n == 0 fails there with a message
 	}
 
+	// RT_HIP_FLAG_PERSISTENT_FRAME: rt keeps one image per window size (src/window.cpp:61-64), so the module may page-lock
+	// it once and render straight into it.  RT_HIP_FRAME=copy withholds the flag (the frame then goes through HBM and one
+	// copy): for a build of rt that may free an image and get the same address and size back between two frames without
+	// calling rt_hip_forget_frame (INTEGRATION.md §3 "The back buffer").
+	uint32_t frame_flags()
+	{
+		static const uint32_t flags = []
+		{
+			const char* frame = std::getenv("RT_HIP_FRAME");
+			return (frame && std::strcmp(frame, "copy") == 0) ? static_cast<uint32_t>(RT_HIP_FLAG_NONE) : static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME);
+		}();
+		return flags;
+	}
+
 	// ModeFlags: 0 = mg_ray_tracer's scatter table; RT_HIP_FLAG_SM_MATERIALS = sm_ray_tracer's (dielectrics refract);
 	// RT_HIP_FLAG_PREVIEW = the one-ray-per-pixel preview of src/renderers/rasterizer.cpp
 	template <uint32_t ModeFlags>
@@ -123,7 +137,7 @@ namespace
 			const char* fixed = std::getenv("RT_HIP_SEED");
 			const uint64_t seed = fixed ? std::strtoull(fixed, nullptr, 0) : ++frame_number;
 
-			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME) | ModeFlags, nullptr, nullptr) != RT_HIP_OK)
+			if (rt_hip_render(ctx, &s, pixels.data(), pixels.size().x, pixels.size().y, seed, frame_flags() | ModeFlags, nullptr, nullptr) != RT_HIP_OK)
 				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
 		}
 	};

@@ -51,7 +51,7 @@ class Scene:
 
     def __del__(self):
         handle, self._handle = getattr(self, "_handle", None), None
-        if handle:
+        if handle and capi is not None and getattr(capi, "host_lib", None) is not None:  # (None during interpreter shutdown)
             capi.host_lib().rt_host_scene_free(handle)
 
     # ---- mutation -------------------------------------------------------------------------------------------
