@@ -140,6 +140,8 @@ struct rt_hip_ctx
 	uint32_t samples_per_pixel = 0, max_bounces = 0;
 	float inverse_view_projection[16]{};
 
+	// big scenes: chunk sums on their way between waves and the pixels' arrival counters (kernels.hpp, rolling_buffers)
+	device_buffer item_sums, pixel_done;
 	device_buffer counters;
 	device_counters* counters_host = nullptr; // page-locked; filled by an asynchronous copy right behind every launch that keeps stats
 	hipEvent_t render_begin = nullptr, render_end = nullptr, counters_copied = nullptr;
@@ -610,6 +612,8 @@ extern "C" void rt_hip_destroy(rt_hip_ctx* ctx)
 	(void)hipDeviceSynchronize();
 	unpin_frame(ctx);
 	ctx->scene_columns.release();
+	ctx->item_sums.release();
+	ctx->pixel_done.release();
 	ctx->counters.release();
 	ctx->frame_rgba.release();
 	ctx->frame_rgb.release();
@@ -1116,19 +1120,35 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	f.inv_w_near = f.uniform_w ? 1.0f / f.k_near[3] : 0.0f;
 	f.inv_w_far = f.uniform_w ? 1.0f / f.k_far[3] : 0.0f;
 
-	bool rolling_tiles = false; // the persistent big-scene kernels pull pixel tiles from a queue whose head must start at 0
+	bool rolling_items = false; // the persistent big-scene kernels draw items from a sequence whose head must start at 0
+	rolling_buffers rolling;
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		// a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
 		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
-		rolling_tiles = big_scene;
-		const queue_params tiles = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);
-		const uint64_t slot_bytes = 4ull * (big_scene ? 2u : 1u) * (static_cast<uint64_t>(tiles.chunks) << tiles.pixels_log2) * 12u;
+		rolling_items = big_scene;
+		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);
+		// small scenes: a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
+		const uint64_t slot_bytes = big_scene ? 0u : 4ull * (static_cast<uint64_t>(queue.chunks) << queue.pixels_log2) * 12u;
 		if (slot_bytes > 48u * 1024u)
 			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %u samples per pixel are more than the kernels hold chunk sums for (4096; the reference clamps to 1000, src/scene.cpp:544)", f.samples_per_pixel);
-		if (static_cast<uint64_t>(tiles.tiles_x) * tiles.tiles_y > 0x7FFFFFFFull) // the tile queue's 32-bit head
-			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %ux%u at %u samples per pixel has too many pixel tiles", width, height, f.samples_per_pixel);
+		// big scenes: they meet in HBM, 16 bytes per chunk of this rank's rows
+		size_t sums_bytes = 0, done_bytes = 0;
+		rolling_buffer_bytes(queue, width, f.local_rows, big_scene, sums_bytes, done_bytes);
+		if (sums_bytes > (64ull << 30))
+			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %ux%u at %u samples per pixel needs %zu GiB for the chunk sums of a scene of this size", width, height, f.samples_per_pixel, sums_bytes >> 30);
+		if (sums_bytes)
+		{
+			RT_HIP_TRY(ctx->item_sums.reserve(sums_bytes));
+			if (ctx->pixel_done.bytes < done_bytes)
+			{
+				// the counters are zero between launches (the lane that folds a pixel puts its counter back): new memory is zeroed once
+				RT_HIP_TRY(ctx->pixel_done.reserve(done_bytes));
+				RT_HIP_TRY(hipMemsetAsync(ctx->pixel_done.ptr, 0, ctx->pixel_done.bytes, s));
+			}
+			rolling.item_sums = ctx->item_sums.as<unsigned long long>();
+			rolling.pixel_done = ctx->pixel_done.as<uint32_t>();
+		}
 	}
 	device_counters* const counters = ctx->counters.as<device_counters>();
 	if (keep_stats)
@@ -1136,15 +1156,15 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		RT_HIP_TRY(hipMemsetAsync(counters, 0, sizeof(device_counters), s));
 		RT_HIP_TRY(hipEventRecord(ctx->render_begin, s));
 	}
-	else if (rolling_tiles)
-		RT_HIP_TRY(hipMemsetAsync(&counters->next_tile, 0, sizeof(counters->next_tile), s)); // (seconds-long launches: not launch-bound)
+	else if (rolling_items)
+		RT_HIP_TRY(hipMemsetAsync(&counters->next_item, 0, sizeof(counters->next_item), s)); // (seconds-long launches: not launch-bound)
 	uint32_t variant = RT_HIP_KERNEL_PREVIEW;
 	if (flags & RT_HIP_FLAG_PREVIEW)
 		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, counters, s);
 	else if (flags & RT_HIP_FLAG_FAST)
-		variant = launch_render_fast(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, counters, ctx->compute_units, ctx->cache, s);
+		variant = launch_render_fast(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
 	else
-		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, counters, ctx->compute_units, ctx->cache, s);
+		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
 	RT_HIP_TRY(hipGetLastError());
 	ctx->launched = true;
 	ctx->last_stream = s;

@@ -355,20 +355,46 @@ namespace rt_hip
 		// the divergent loop no longer spills to VGPR lanes (3.12 -> 3.05 ms).  6 waves are slower everywhere.  The
 		// big-scene modes get the registers of 5 waves per SIMD.
 		//
-		// ROLLING TILES (NS < 0).  In a big scene a trip is one closest-hit scan over all primitives — the same cost for a
+		// ROLLING ITEMS (NS < 0).  In a big scene a trip is one closest-hit scan over all primitives — the same cost for a
 		// wave with one lane holding a ray as for a wave with 64 — so what matters is that every lane holds a ray in every
-		// trip.  The big-scene kernels are therefore launched persistent: every wave pulls pixel tile after pixel tile from
-		// one launch-wide counter and keeps TWO tiles open — lanes that find the current tile handed out start on the next
-		// one while the stragglers of the previous tile finish — and folds a tile's chunk sums into its pixels when the
-		// tile's last item comes in.  Lanes idle only at the very end of the launch.  (For small scenes the same scheme is
-		// SLOWER: there the per-trip cost is the shading code, and lanes that never start together lose the phase
+		// trip, and that all waves of the launch run dry at the same moment.  The big-scene kernels are therefore launched
+		// persistent, and their unit of hand-out is the single ITEM: all (pixel, chunk) items of this rank's rows form ONE
+		// launch-wide sequence (pixel-major, bottom row first); a wave draws small blocks of consecutive items from one
+		// counter — one block ahead, so that the atomic's latency is off the path — and gives them to its lanes as they
+		// fall free, in the same trip.  A pixel's chunks may end up in different waves, on different CUs and XCDs: every
+		// finished chunk sum goes to a scratch slot in HBM (write-through stores, drained), then the pixel's arrival
+		// counter is incremented; whoever brings the LAST chunk of a pixel reads all of them back (loads that bypass the
+		// non-coherent caches), folds them in chunk order and writes the pixel.  Which lane of which wave that is cannot
+		// change a bit of the result.
+		// Round 2 handed out pixel TILES (128 items, two open per wave, sums in LDS).  Measured with per-wave clocks on the
+		// 100 000-sphere frame (profiles/r03/config5_streamed/wave_tail_*.txt): the queue ran dry after 74 % of the launch
+		// and a wave then still owned up to 256 items — four rounds of 34 trips for its lanes — so 20 % of all wave-time
+		// was spent waiting for the slowest waves.  With items the stragglers' excess is one item, not four tiles' worth.
+		// (For small scenes the per-trip cost is the shading code, and lanes that never start together lose the phase
 		// coherence that keeps it short — profiles/r01/queue_shape_sweep.txt.  They keep one tile per wave.)
-		__device__ __forceinline__ uint32_t fetch_tile(device_counters* counters) // call converged
+		__device__ __forceinline__ unsigned long long fetch_items(device_counters* counters, uint32_t count) // call converged
 		{
-			uint32_t id = 0;
+			unsigned long long base = 0;
 			if ((threadIdx.x & 63u) == 0)
-				id = atomicAdd(&counters->next_tile, 1u);
-			return __builtin_amdgcn_readfirstlane(id);
+				base = atomicAdd(&counters->next_item, static_cast<unsigned long long>(count));
+			const uint32_t lo = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base));
+			const uint32_t hi = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(base >> 32));
+			return (static_cast<unsigned long long>(hi) << 32) | lo;
+		}
+
+		// a chunk sum on its way between waves: 16 bytes per item, written and read with agent-scope accesses only
+		// (global_store / global_load ... sc1: through to memory, past this CU's L1 and this XCD's L2)
+		__device__ __forceinline__ void publish_sum(unsigned long long* slot, vec3 sum)
+		{
+			const unsigned long long xy = (static_cast<unsigned long long>(__float_as_uint(sum.y)) << 32) | __float_as_uint(sum.x);
+			__hip_atomic_store(slot, xy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(reinterpret_cast<uint32_t*>(slot + 1), __float_as_uint(sum.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+		__device__ __forceinline__ vec3 read_sum(unsigned long long* slot)
+		{
+			const unsigned long long xy = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const uint32_t z = __hip_atomic_load(reinterpret_cast<uint32_t*>(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			return { __uint_as_float(static_cast<uint32_t>(xy)), __uint_as_float(static_cast<uint32_t>(xy >> 32)), __uint_as_float(z) };
 		}
 
 		template <int NS, bool SM>
@@ -379,7 +405,9 @@ namespace rt_hip
 																	  const float4* __restrict__ geometry, // = s.primitive_geometry, as a plain read-only argument
 																	  uint32_t* __restrict__ out_rgba,
 																	  float* __restrict__ out_rgb,
-																	  device_counters* __restrict__ counters)
+																	  device_counters* __restrict__ counters,
+																	  unsigned long long* item_sums, // [NS < 0] chunk sums in transit: 16 bytes per item
+																	  uint32_t* pixel_done)			 // [NS < 0] chunks arrived per pixel (0 between launches)
 		{
 			extern __shared__ float4 lds[];
 			// [NS > 0] 8 geometry + 8 shading float4s, 8 metal flags | [NS == 0] all primitives; then the chunk slots
@@ -414,8 +442,8 @@ namespace rt_hip
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
 			const uint32_t items = q.chunks << q.pixels_log2; // of one pixel tile: P x K
-			// chunk-sum slots of this wave's tile (two open tiles when rolling)
-			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * (ROLLING ? 2u * items : items) * 3u;
+			// chunk-sum slots of this wave's tile (one tile per wave; the rolling kernels keep no sums in LDS)
+			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * items * 3u;
 			const uint32_t tile_w = 1u << q.tile_w_log2;
 			const uint32_t tile_h = (1u << q.pixels_log2) >> q.tile_w_log2;
 
@@ -425,23 +453,14 @@ namespace rt_hip
 			const uint32_t tile_y0 = (gridDim.y - 1u - blockIdx.y) * tile_h;
 			uint32_t next_item = 0; // wave-uniform queue head
 
-			// rolling tiles: ids run bottom row first
-			const uint32_t total_tiles = q.tiles_x * q.tiles_y;
-			const auto tile_origin = [&](uint32_t id, uint32_t& x0, uint32_t& y0)
-			{
-				const uint32_t row = id / q.tiles_x;
-				x0 = (id - row * q.tiles_x) << q.tile_w_log2;
-				y0 = (q.tiles_y - 1u - row) * tile_h;
-			};
-			uint32_t tile0 = 0, tile1 = 0;		 // ids of the tiles in the two slot buffers
-			uint32_t pending0 = 0, pending1 = 0; // their items not yet completed; 0 = the buffer is free
-			uint32_t cur = 1;					 // buffer being handed out
-			uint32_t cur_next = items;			 // its next item (== items: all handed out)
-			uint32_t cur_x0 = 0, cur_y0 = 0;	 // its pixel origin
-			bool dry = false;					 // the launch-wide queue has run out
-			uint32_t prefetched = 0;			 // the id the next opening will use: the atomic's latency is off the path
+			// rolling items: the launch-wide sequence, the block this wave is handing out, the block drawn ahead
+			const unsigned long long total_items = static_cast<unsigned long long>(p.width) * p.local_rows * q.chunks;
+			unsigned long long block_next = 0, block_end = 0; // [block_next, block_end): not yet given to a lane
+			unsigned long long prefetched = 0;				  // first item of the block after that
+			uint32_t prefetched_count = 64u;				  // (the first block is a whole wave's worth: every lane starts at once)
+			bool dry = false;								  // the launch-wide sequence has run out
 			if (ROLLING)
-				prefetched = fetch_tile(counters);
+				prefetched = fetch_items(counters, prefetched_count);
 #ifdef RT_HIP_WAVE_CLOCKS
 			const unsigned long long clock_start = wall_clock64();
 			unsigned long long clock_dry = 0;
@@ -453,8 +472,7 @@ namespace rt_hip
 			constexpr bool SCALAR_SEGMENTS = NS >= 1 && NS <= 4;
 			unsigned long long wave_segments = 0;
 			uint32_t lane_segments = 0;
-			uint32_t slot = 0;	  // chunk-sum slot of the item in flight on this lane ([buffer * items +] item)
-			bool holding = false; // rolling: the lane has been given an item that is not yet accounted for as completed
+			uint32_t slot = 0; // chunk-sum slot of the item in flight on this lane; rolling: its pixel's place in the hand-out order
 			// what the lane does in the current trip:
 			//   free    - between items                       restart - has a sample to start (needs a primary ray)
 			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
@@ -509,12 +527,32 @@ namespace rt_hip
 					}
 				}
 			};
-			const auto fold_rolling = [&](uint32_t buffer, uint32_t id)
+			// rolling: the lane's item is finished.  One chunk per pixel (<= 16 samples): the sum IS the pixel.  Otherwise the
+			// sum is published, the pixel's arrival counter incremented, and the lane that brings the last chunk folds them.
+			const auto complete_item = [&]()
 			{
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // the sums were parked by other lanes of this wave
-				uint32_t x0, y0;
-				tile_origin(id, x0, y0);
-				fold_tile(slots + buffer * items * 3u, x0, y0);
+				const uint32_t row = slot / p.width; // hand-out order: bottom row first
+				const uint32_t lx = slot - row * p.width;
+				const uint32_t ly = p.local_rows - 1u - row;
+				if (q.chunks == 1u) // (wave-uniform)
+				{
+					finish_pixel(st.chunk_sum, p, lx, ly, out_rgba, out_rgb);
+					return;
+				}
+				const uint32_t chunk = (st.sample_end - 1u) / sample_chunk;
+				unsigned long long* const sums = item_sums + 2u * static_cast<size_t>(slot) * q.chunks;
+				publish_sum(sums + 2u * chunk, st.chunk_sum);
+				asm volatile("s_waitcnt vmcnt(0) ; the sum has left before the arrival is counted" ::: "memory");
+				const uint32_t before = __hip_atomic_fetch_add(&pixel_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				if (before + 1u == q.chunks)
+				{
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below the counter's answer)
+					vec3 colour = read_sum(sums);
+					for (uint32_t c = 1; c < q.chunks; c++)
+						colour = colour + read_sum(sums + 2u * c);
+					__hip_atomic_store(&pixel_done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // as the next launch expects it
+					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+				}
 			};
 
 			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
@@ -525,9 +563,14 @@ namespace rt_hip
 					mode = lane_restart;
 				else
 				{
-					slots[slot * 3u + 0u] = st.chunk_sum.x;
-					slots[slot * 3u + 1u] = st.chunk_sum.y;
-					slots[slot * 3u + 2u] = st.chunk_sum.z;
+					if (ROLLING)
+						complete_item();
+					else
+					{
+						slots[slot * 3u + 0u] = st.chunk_sum.x;
+						slots[slot * 3u + 1u] = st.chunk_sum.y;
+						slots[slot * 3u + 2u] = st.chunk_sum.z;
+					}
 					mode = lane_free;
 				}
 			};
@@ -670,24 +713,28 @@ namespace rt_hip
 				// ---- hand out items to free lanes (converged): a lane whose chunk just ended with a miss restarts right below ----
 				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
+				// a free lane starts on chunk `chunk` of the pixel at (lx, ly) of this rank's rows
+				const auto start_item = [&](uint32_t lx, uint32_t ly, uint32_t chunk)
+				{
+					const uint32_t gy = global_row(ly, p);
+					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
+					st.fx = static_cast<float>(lx);
+					st.fy = static_cast<float>(gy);
+					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
+					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
+					st.sample = chunk * sample_chunk;
+					st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+					mode = lane_restart;
+				};
+				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
 				const auto take_item = [&](uint32_t item, uint32_t x0, uint32_t y0)
 				{
 					const uint32_t pixel = item & ((1u << q.pixels_log2) - 1u); // chunk-major item order
 					const uint32_t chunk = item >> q.pixels_log2;
 					const uint32_t lx = x0 + (pixel & (tile_w - 1u));
 					const uint32_t ly = y0 + (pixel >> q.tile_w_log2);
-					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
 					if (lx < p.width && ly < p.local_rows)
-					{
-						const uint32_t gy = global_row(ly, p);
-						st.fx = static_cast<float>(lx);
-						st.fy = static_cast<float>(gy);
-						st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
-						st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
-						st.sample = chunk * sample_chunk;
-						st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
-						mode = lane_restart;
-					}
+						start_item(lx, ly, chunk);
 					// else: a pixel outside the frame — the item is empty, ask again next trip
 				};
 				if (!ROLLING && asking != 0)
@@ -709,34 +756,16 @@ namespace rt_hip
 				}
 				if (ROLLING && asking != 0)
 				{
-					// items completed since the last hand-out; a tile whose last item is in gets folded and its buffer freed
-					const bool completed = mode == lane_free && holding;
-					const uint32_t done0 = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(completed && slot < items)));
-					const uint32_t done1 = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(completed && slot >= items)));
-					holding = holding && mode != lane_free;
-					if (done0 != 0)
-					{
-						pending0 -= done0;
-						if (pending0 == 0)
-							fold_rolling(0u, tile0);
-					}
-					if (done1 != 0)
-					{
-						pending1 -= done1;
-						if (pending1 == 0)
-							fold_rolling(1u, tile1);
-					}
-
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
 					const uint32_t want = static_cast<uint32_t>(__builtin_popcountll(asking));
 					uint32_t served = 0; // asking lanes given an item so far, in rank order
 					while (served < want)
 					{
-						if (cur_next == items) // the current tile is handed out: open the next one in the other buffer
+						if (block_next == block_end) // this wave's block is used up: on to the one drawn ahead
 						{
-							if (dry || (cur ? pending0 : pending1) != 0) // ...unless its previous tile still has items in flight
+							if (dry)
 								break;
-							if (prefetched >= total_tiles)
+							if (prefetched >= total_items)
 							{
 								dry = true;
 #ifdef RT_HIP_WAVE_CLOCKS
@@ -744,28 +773,35 @@ namespace rt_hip
 #endif
 								break;
 							}
-							cur ^= 1u;
-							if (cur)
-								tile1 = prefetched, pending1 = items;
-							else
-								tile0 = prefetched, pending0 = items;
-							tile_origin(prefetched, cur_x0, cur_y0);
-							cur_next = 0;
-							prefetched = fetch_tile(counters);
+							block_next = prefetched;
+							block_end = min(prefetched + prefetched_count, total_items);
+							prefetched_count = q.block_items;
+							prefetched = fetch_items(counters, prefetched_count);
 						}
-						const uint32_t take = min(want - served, items - cur_next); // >= 1: the loop always advances
+						const uint32_t take = static_cast<uint32_t>(min(static_cast<unsigned long long>(want - served), block_end - block_next)); // >= 1
 						if (mode == lane_free && rank - served < take) // served <= rank < served + take
 						{
-							const uint32_t item = cur_next + (rank - served);
-							slot = cur * items + item;
-							holding = true; // (an item outside the frame stays `free` and counts as completed at the next hand-out)
-							take_item(item, cur_x0, cur_y0);
+							// item -> (pixel in hand-out order, chunk): pixel-major, so that a pixel's chunks are started together
+							const unsigned long long item = block_next + (rank - served);
+							uint32_t pixel, chunk;
+							if ((total_items >> 32) == 0) // (wave-uniform)
+							{
+								pixel = static_cast<uint32_t>(item) / q.chunks;
+								chunk = static_cast<uint32_t>(item) - pixel * q.chunks;
+							}
+							else
+							{
+								pixel = static_cast<uint32_t>(item / q.chunks);
+								chunk = static_cast<uint32_t>(item - static_cast<unsigned long long>(pixel) * q.chunks);
+							}
+							const uint32_t row = pixel / p.width; // bottom row first
+							slot = pixel;
+							start_item(pixel - row * p.width, p.local_rows - 1u - row, chunk);
 						}
 						served += take;
-						cur_next += take;
+						block_next += take;
 					}
-					// lanes left without an item while the queue is not dry (the other buffer is still draining) ask again next trip
-					if (dry && mode == lane_free && !holding)
+					if (dry && mode == lane_free)
 						mode = lane_retired;
 				}
 				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
@@ -1214,6 +1250,7 @@ namespace rt_hip
 							 uint32_t* d_rgba8,
 							 float* d_rgb_f32,
 							 device_counters* d_counters,
+							 const rolling_buffers& rolling,
 							 uint32_t compute_units,
 							 launch_cache& cache,
 							 hipStream_t stream)
@@ -1239,7 +1276,7 @@ namespace rt_hip
 				}
 				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(known.per_cu)));
 			}
-			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters);
+			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 		}
 
 		template <int NS>
@@ -1253,16 +1290,17 @@ namespace rt_hip
 						  uint32_t* d_rgba8,
 						  float* d_rgb_f32,
 						  device_counters* d_counters,
+						  const rolling_buffers& rolling,
 						  uint32_t compute_units,
 						  launch_cache& cache,
 						  hipStream_t stream)
 		{
 #ifndef RT_HIP_FAST_BUILD // (the API refuses RT_HIP_FLAG_FAST together with RT_HIP_FLAG_SM_MATERIALS)
 			if (sm)
-				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
+				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			else
 #endif
-				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
+				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 		}
 	}
 
@@ -1292,15 +1330,11 @@ namespace rt_hip
 		uint32_t pixels_log2;
 		if (big_scene)
 		{
-			// rolling tiles: at least 128 items per tile (two per lane) — with two tiles open per wave the stragglers of
-			// one tile are then normally in before the next one is handed out; otherwise as small as possible (the queue
-			// balances the chip at tile granularity, and the slots of two tiles per wave live in LDS)
+			// rolling items: no tiles at all (the fields below describe the frame as 1 x 1 tiles and are not used); a wave
+			// draws 8 items at a time, one block ahead — small enough that a wave sits on at most 15 reserved items when
+			// the sequence runs dry, large enough that the counter sees one atomic per wave every few trips
 			pixels_log2 = 0;
-#ifndef RT_HIP_BIG_TILE_ITEMS
-#define RT_HIP_BIG_TILE_ITEMS 128u
-#endif
-			while (pixels_log2 < 7u && (q.chunks << pixels_log2) < RT_HIP_BIG_TILE_ITEMS)
-				pixels_log2++;
+			q.block_items = 8u;
 		}
 		else
 		{
@@ -1324,6 +1358,16 @@ namespace rt_hip
 		return q;
 	}
 
+	void rolling_buffer_bytes(const queue_params& queue, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes)
+	{
+		item_sums_bytes = pixel_done_bytes = 0;
+		if (!big_scene || queue.chunks <= 1u) // one chunk per pixel: the lane that traced it writes the pixel
+			return;
+		const size_t pixels = static_cast<size_t>(width) * local_rows;
+		item_sums_bytes = pixels * queue.chunks * 16u;
+		pixel_done_bytes = pixels * sizeof(uint32_t);
+	}
+
 #endif // !RT_HIP_FAST_BUILD
 
 	uint32_t launch_render(const frame_params& frame,
@@ -1333,6 +1377,7 @@ namespace rt_hip
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
+						   const rolling_buffers& rolling,
 						   uint32_t compute_units,
 						   launch_cache& cache,
 						   hipStream_t stream)
@@ -1345,39 +1390,39 @@ namespace rt_hip
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene);
 		const uint32_t items = queue.chunks << queue.pixels_log2;
 		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
-		// the device keeps resident, and no more waves than tiles
-		const uint64_t total_tiles = static_cast<uint64_t>(queue.tiles_x) * queue.tiles_y;
-		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_tiles + 3u) / 4u))) // capped to the resident count at launch
+		// the device keeps resident, and no more lanes than items
+		const uint64_t total_items = static_cast<uint64_t>(frame.width) * frame.local_rows * queue.chunks;
+		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_items + block_threads - 1u) / block_threads))) // capped to the resident count at launch
 									: dim3((queue.tiles_x + 3u) / 4u, queue.tiles_y);
-		const size_t slot_bytes = static_cast<size_t>(block_threads / 64u) * (big_scene ? 2u : 1u) * items * 3u * sizeof(float);
+		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * items * 3u * sizeof(float);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
 			switch (scene.n_spheres)
 			{
-				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
-				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream); break;
+				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
 			}
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
 			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
-			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
+			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_STREAMED)
 		{
-			launch_queue<-2>(sm, frame, queue, small, scene, grid, slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
+			launch_queue<-2>(sm, frame, queue, small, scene, grid, 0, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			return variant;
 		}
-		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4) + slot_bytes, d_rgba8, d_rgb_f32, d_counters, compute_units, cache, stream);
+		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4), d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 		return variant;
 	}
 

@@ -85,18 +85,32 @@ namespace rt_hip
 	// pixel sums are taken in chunks of this many consecutive samples (arithmetic contract; see oracle/cpu_ref.cpp)
 	constexpr uint32_t sample_chunk = 16;
 
-	// Work distribution.  The frame is cut into pixel tiles of P = 2^pixels_log2 pixels; a tile is P x K work items
-	// (K = sample chunks per pixel).  Small scenes: one tile per wave, launched as a grid of tiles.  Big scenes (tiled /
-	// streamed kernels): a persistent launch whose waves pull tiles from one launch-wide queue (device_counters::next_tile),
-	// tile ids running bottom row first.
+	// Work distribution.  The unit of work is one ITEM = one chunk of 16 consecutive samples of one pixel (K = chunks per
+	// pixel).  Small scenes: the frame is cut into pixel tiles of P = 2^pixels_log2 pixels, one tile (P x K items) per wave,
+	// launched as a grid of tiles.  Big scenes (tiled / streamed kernels): a persistent launch whose waves draw single
+	// items, in blocks of `block_items`, from one launch-wide sequence (device_counters::next_item), pixel-major, bottom
+	// row first; a pixel's chunk sums meet in HBM (rolling_buffers).
 	struct queue_params
 	{
 		uint32_t chunks;		   // K = ceil(spp / sample_chunk)
-		uint32_t pixels_log2;	   // P
+		uint32_t pixels_log2;	   // P (small scenes)
 		uint32_t tile_w_log2;	   // a tile is 2^tile_w_log2 columns wide
 		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
+		uint32_t block_items;	   // big scenes: items a wave draws from the launch-wide sequence at a time
 	};
 	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene);
+
+	// What the big-scene kernels exchange chunk sums through (owned by the context, grown on demand):
+	//   item_sums   16 bytes per item of this rank's rows (a chunk sum on its way to the lane that folds the pixel);
+	//               not needed when a pixel is one chunk
+	//   pixel_done  one arrival counter per pixel; zero between launches (the folding lane puts it back)
+	struct rolling_buffers
+	{
+		unsigned long long* item_sums = nullptr;
+		uint32_t* pixel_done = nullptr;
+	};
+	// bytes of the two buffers for a launch (0, 0 for the small-scene kernels)
+	void rolling_buffer_bytes(const queue_params& queue, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes);
 
 	struct device_counters
 	{
@@ -104,7 +118,7 @@ namespace rt_hip
 		// once, and 130 000 atomics on ONE address serialise at about 12 ns each — more than a small launch takes
 		static constexpr unsigned segment_counters = 64;
 		unsigned long long segments[segment_counters];
-		unsigned int next_tile; // head of the tile queue of the big-scene kernels; zeroed with the rest before every launch
+		unsigned long long next_item; // head of the item sequence of the big-scene kernels; zeroed before every launch
 #ifdef RT_HIP_REGION_COUNTERS
 		static constexpr unsigned regions = 13; // experiment variant only (kernels.hip, RT_HIP_REGION)
 		unsigned long long region_runs[regions], region_lanes[regions];
@@ -148,6 +162,7 @@ namespace rt_hip
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
+						   const rolling_buffers& rolling, // big scenes: sized by rolling_buffer_bytes(), pixel_done zeroed once
 						   uint32_t compute_units, // of the device: the big-scene kernels are launched persistent
 						   launch_cache& cache,
 						   hipStream_t stream);
@@ -160,6 +175,7 @@ namespace rt_hip
 								uint32_t* d_rgba8,
 								float* d_rgb_f32,
 								device_counters* d_counters,
+								const rolling_buffers& rolling,
 								uint32_t compute_units,
 								launch_cache& cache,
 								hipStream_t stream);
