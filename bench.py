@@ -436,6 +436,7 @@ def main() -> None:
                         phase_samples.append(rank_tracer.phases())
                         return s
 
+                    settle(own_share)  # (bringing the communicator up left the GPU idle for a second or two: clocks up again first)
                     lib_elapsed, lib_kernels = timed(measured_step, lambda s: s["render_ms"])
                     phase_samples[:] = phase_samples[-args.steps :]
                     infos = [None] * world

@@ -25,10 +25,13 @@
 //       tiled    (anything larger): primitives stream from the SoA columns in HBM/L2 through one LDS tile of 1024
 //                shared by the workgroup's waves (coalesced dword loads per column, radius squared on the way in);
 //                the workgroup moves in lock step, one path segment per trip, with barriers around each tile;
-//       streamed (opt-in): the resident loop reading the primitive table with wave-uniform scalar loads from HBM/L2.
-//     The two big-scene modes are launched persistent and pull pixel tiles from a launch-wide queue, two open per wave
-//     ("rolling tiles", see render_queue): there a trip costs one scan over all primitives whatever the number of lanes
-//     holding a ray, so lane occupancy is everything.
+//       streamed (larger scenes from 32 samples per pixel): the resident loop reading the primitive table with
+//                wave-uniform scalar loads from HBM/L2, the next group's load issued before this group's probes; a
+//                wave left with a handful of rays walks the table once per ray with all 64 lanes instead.
+//     The two big-scene modes are launched persistent and draw single (pixel, chunk) items from ONE launch-wide
+//     sequence; a pixel's chunk sums meet in HBM ("rolling items", see render_queue): there a trip costs one scan
+//     over all primitives whatever the number of lanes holding a ray, so lane occupancy is everything — and so is
+//     that the whole launch runs dry at one moment.
 // No MFMA: this is intersection arithmetic (subtract / dot / compare / sqrt), not a contraction.
 //
 // This file is compiled TWICE into librt_hip.so: as it stands (the parity contract: -ffp-contract=off, exactly rounded
@@ -224,6 +227,73 @@ namespace rt_hip
 			}
 			for (uint32_t i = groups * 4; i < count; i++)
 				test_sphere(best, o, d, table[i], i);
+		}
+
+		// SPARSE WAVES (streamed kernel).  A scan costs a wave the same whether one lane holds a ray or all 64 do.  At the
+		// end of a launch — and in small frames of big scenes — waves hold a handful of rays: such a wave turns the scan
+		// around and walks the table ONCE PER RAY with all 64 lanes, lane l testing spheres l, l + 64, ... (coalesced 16-byte
+		// loads), followed by a wave-wide minimum.  test_spheres keeps the first sphere at the smallest accepted distance
+		// (`hit_dist <= *hit` -> continue, mg_ray_tracer.cpp:74), i.e. the lexicographic minimum of (t, index) over the
+		// accepted candidates; every lane takes that minimum over its own spheres in index order, and the 64 partial results
+		// are reduced with the same order — accepted distances are >= 0.001, so their bit patterns order like the numbers.
+		// The one thing a minimum cannot reproduce is a NaN distance (a degenerate ray), which the sequential rule lets
+		// in and then never displaces consistently: if any lane meets one, the ray is reported as not scanned and goes
+		// through the sequential scan.  The per-sphere arithmetic is finish_sphere's, bit for bit.
+		constexpr uint32_t sparse_wave_rays = 8;	 // a wave holding at most this many rays scans together
+		constexpr uint32_t sparse_min_spheres = 1024; // (below that a sequential scan is a few microseconds anyway)
+
+		__device__ __forceinline__ void test_sphere_alone(candidate& best, bool& met_nan, vec3 o, vec3 d, float4 s, uint32_t index)
+		{
+			const sphere_probe p = probe_sphere(o, d, s);
+			if (p.pos) // a per-lane branch: every lane looks at a different sphere, and few spheres lie on a ray's line
+			{
+				const float f = sqrt_rn(p.disc);
+				const float t = (p.e2 < s.w) ? p.a + f : p.a - f;
+				met_nan = met_nan || t != t;
+				const bool accept = !(t < min_hit_dist) && !(best.have && best.t <= t);
+				best.t = accept ? t : best.t;
+				best.index = accept ? index : best.index;
+				best.have = best.have || accept;
+			}
+		}
+
+		// call converged, with a wave-uniform ray; returns false if the ray has to be scanned sequentially instead
+		__device__ __forceinline__ bool scan_spheres_together(candidate& found, vec3 o, vec3 d, const float4* __restrict__ table, uint32_t count, uint32_t lane)
+		{
+			candidate mine = { 0.0f, 0u, false };
+			bool met_nan = false;
+			uint32_t i = lane;
+			// four independent loads in flight per lane: the walk is bound by L2 latency, not by arithmetic.  (The registers
+			// they take cost the kernel one wave per SIMD of occupancy, 5 instead of 6, which the sequential scan — bound by
+			// vector issue — does not miss: config 5 5.61 against 5.69 s with two loads in flight, 10 000 spheres 277 against
+			// 290 ms; profiles/r03/config5_streamed/sparse_waves_ab.txt.)
+			for (; i + 192u < count; i += 256u)
+			{
+				const float4 s0 = table[i], s1 = table[i + 64u], s2 = table[i + 128u], s3 = table[i + 192u];
+				test_sphere_alone(mine, met_nan, o, d, s0, i);
+				test_sphere_alone(mine, met_nan, o, d, s1, i + 64u);
+				test_sphere_alone(mine, met_nan, o, d, s2, i + 128u);
+				test_sphere_alone(mine, met_nan, o, d, s3, i + 192u);
+			}
+			for (; i < count; i += 64u)
+				test_sphere_alone(mine, met_nan, o, d, table[i], i);
+			if (__builtin_amdgcn_ballot_w64(met_nan) != 0)
+				return false;
+			uint32_t key_t = mine.have ? __float_as_uint(mine.t) : 0xFFFFFFFFu; // (no accepted distance has this pattern: it is a NaN's)
+			uint32_t key_i = mine.have ? mine.index : 0xFFFFFFFFu;
+#pragma unroll
+			for (int offset = 32; offset > 0; offset >>= 1)
+			{
+				const uint32_t other_t = __shfl_xor(key_t, offset, 64);
+				const uint32_t other_i = __shfl_xor(key_i, offset, 64);
+				const bool take = other_t < key_t || (other_t == key_t && other_i < key_i);
+				key_t = take ? other_t : key_t;
+				key_i = take ? other_i : key_i;
+			}
+			found.have = key_t != 0xFFFFFFFFu;
+			found.t = found.have ? __uint_as_float(key_t) : 0.0f;
+			found.index = found.have ? key_i : 0u;
+			return true;
 		}
 
 		// cooperative copy of `count` primitives starting at `first` from the SoA columns into float4 LDS slots;
@@ -611,6 +681,38 @@ namespace rt_hip
 				// RESTARTS with the next sample's primary ray (two draws, a new direction).  Both end in the same
 				// operations — random draws and the normalisation of a direction — which are therefore issued once for
 				// the whole wave; only the pieces that really differ run under their own lane masks.
+				// streamed kernel, a wave with a handful of rays: one cooperative scan per ray (see scan_spheres_together)
+				candidate together = { 0.0f, 0u, false };
+				bool scanned_together = false;
+#ifdef RT_HIP_NO_SPARSE_WAVES // (experiment builds: the kernel without the cooperative scan)
+				constexpr bool sparse_waves = false;
+#else
+				constexpr bool sparse_waves = true;
+#endif
+				if (sparse_waves && NS == -2 && s.n_spheres >= sparse_min_spheres)
+				{
+					unsigned long long holders = __builtin_amdgcn_ballot_w64(tracing);
+					if (holders != 0 && static_cast<uint32_t>(__builtin_popcountll(holders)) <= sparse_wave_rays)
+					{
+						while (holders != 0) // (wave-uniform)
+						{
+							const int src = __builtin_ctzll(holders);
+							holders &= holders - 1u;
+							const vec3 o = { __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.origin.x), src)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.origin.y), src)),
+											 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.origin.z), src)) };
+							const vec3 d = { __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.dir.x), src)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.dir.y), src)),
+											 __int_as_float(__builtin_amdgcn_readlane(__float_as_int(st.dir.z), src)) };
+							candidate found;
+							const bool clean = scan_spheres_together(found, o, d, geometry, s.n_spheres, lane);
+							if (clean && lane == static_cast<uint32_t>(src))
+							{
+								together = found;
+								scanned_together = true;
+							}
+						}
+					}
+				}
+
 				bool shade = false;
 				vec3 normal, base, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
 				float4 shading;
@@ -669,11 +771,14 @@ namespace rt_hip
 						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
 						const float4* const primitives = NS == 0 ? lds : geometry;
 						scan_lds<false>(planes, st.origin, st.dir, primitives + s.n_spheres, s.n_planes, 0);
-#ifndef RT_HIP_NO_STREAM_PREFETCH
 						if (NS == -2)
-							scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
+						{
+							if (scanned_together)
+								spheres = together;
+							else
+								scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
+						}
 						else
-#endif
 							scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
 						uint32_t index;
 						kind = select_hit(spheres, planes, distance, index);

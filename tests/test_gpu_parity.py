@@ -232,8 +232,8 @@ def test_random_scenes_are_bit_exact(tracer, case):
 
 @pytest.mark.parametrize("case", range(6))
 def test_random_scenes_on_frames_with_more_pixel_tiles_than_persistent_waves(tracer, case):
-    """The big-scene kernels pull pixel tiles from a launch-wide queue, two open per wave: on a 1600x900 frame there are
-    11 250 tiles for at most 7168 waves, so buffers are re-opened while stragglers of the previous tile are in flight."""
+    """The big-scene kernels draw their work items from ONE launch-wide sequence and a pixel's chunks meet in HBM: on a
+    1600x900 frame there are more items than the persistent launch has lanes, so every wave draws many blocks."""
     rng = np.random.default_rng(7000 + case)
     spheres, planes, materials, camera = random_scene(rng)
     width, height = 1600, 900
@@ -491,6 +491,75 @@ def test_config5_synthetic_100k_full_size(tracer, flags, kernel):
     owned = [y for y in range(height) if (y // 8) % 8 == rank]
     assert np.array_equal(part[: len(owned)], rgba[owned])
     assert share_stats["primary_samples"] == len(owned) * width * spp
+
+
+def _sphere_field(rng, count):
+    """`count` small spheres over a ground sphere, a few materials of every scatter kind; camera looking down at them."""
+    materials = [(0, 1, 1, 1, 1, 0.5, 0.5), (1, 0.9, 0.9, 0.9, 1, 0.1, 0.8), (0, 0.3, 0.6, 0.9, 1, 0.5, 0.5), (2, 1, 1, 1, 1, 0.0, 1.5), (1, 0.8, 0.6, 0.2, 1, 0.4, 0.8)]
+    spheres = [(0.0, -1000.0, 0.0, 1000.0, 0)]
+    for _ in range(count - 1):
+        r = rng.uniform(0.05, 0.3)
+        spheres.append((rng.uniform(-12, 12), r, rng.uniform(-24, 0), r, int(rng.integers(1, len(materials)))))
+    camera = rt_amd.Scene.parse("").set_camera((0.0, 4.0, 3.0), (0.0, -0.35, -1.0))
+    return spheres, materials, camera
+
+
+@pytest.mark.parametrize("count,width,height,spp", [(1024, 16, 9, 20), (1500, 33, 17, 40), (5000, 8, 3, 70), (100000, 24, 13, 3), (1500, 200, 113, 33)])
+@pytest.mark.parametrize("flags", [FORCE_STREAMED, FORCE_STREAMED | SM], ids=["mg", "sm"])
+def test_waves_with_a_handful_of_rays_scan_together(tracer, count, width, height, spp, flags):
+    """The streamed kernel's sparse-wave path: a wave that holds at most 8 rays walks the sphere table once per ray with all
+    64 lanes and takes a wave-wide (distance, index) minimum instead of scanning sequentially.  Small frames of big scenes
+    are ALL sparse waves (8 x 3 pixels: one wave, a handful of lanes); in the bigger ones it is how every wave ends.
+    Chunks of a pixel are traced by different waves and folded through HBM (17 to 70 samples: 2 to 5 chunks)."""
+    rng = np.random.default_rng(count + width)
+    spheres, materials, camera = _sphere_field(rng, count)
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, [], materials, samples_per_pixel=spp, max_bounces=7, inverse_view_projection=ivp)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=count, sm_materials=bool(flags & SM))
+    for _ in range(2):  # (the second launch finds the pixels' arrival counters as the first one left them: zero)
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=count, flags=flags, want_rgb=True)
+        assert stats["kernel"] == "streamed"
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{count} spheres {width}x{height}x{spp}")
+        assert stats["segments"] == want_stats["segments"]
+    assert len(np.unique(want_rgba)) > 10
+
+
+def test_equal_distances_go_to_the_lowest_index_whichever_way_the_scan_runs(tracer):
+    """test_spheres keeps the FIRST sphere at the smallest distance (mg_ray_tracer.cpp:74).  1100 identical spheres stacked on
+    three sites, indices interleaved, with differently coloured materials: the winner of every tie must be the lowest index
+    in the sequential scan (full waves) and in the cooperative one (a frame so small that every wave is sparse)."""
+    materials = [(0, 1.0, 0.1, 0.1, 1, 0.5, 0.9), (0, 0.1, 1.0, 0.1, 1, 0.5, 0.9), (0, 0.1, 0.1, 1.0, 1, 0.5, 0.9), (0, 0.9, 0.9, 0.9, 1, 0.5, 0.5)]
+    sites = [(-1.2, 0.5, -1.0), (0.0, 0.5, -1.5), (1.2, 0.5, -1.0)]
+    spheres = [(0.0, -1000.0, 0.0, 1000.0, 3)]
+    for i in range(1100):
+        site = sites[i % 3]
+        spheres.append((*site, 0.5, (i // 3 + i) % 3))  # the first sphere of every site has a different material
+    camera = rt_amd.Scene.parse("").set_camera((0.0, 1.0, 3.0), (0.0, -0.1, -1.0))
+    for width, height, spp in [(12, 7, 5), (160, 90, 2)]:
+        ivp = camera.describe(width, height).inverse_view_projection[:]
+        pod = rt_amd.scene_from_arrays(spheres, [], materials, samples_per_pixel=spp, max_bounces=4, inverse_view_projection=ivp)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=5)
+        for flags in (FORCE_STREAMED, FORCE_TILED):
+            got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=5, flags=flags, want_rgb=True)
+            assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"stacked spheres {width}x{height} ({stats['kernel']})")
+            assert stats["segments"] == want_stats["segments"]
+
+
+def test_degenerate_rays_take_the_sequential_scan(tracer):
+    """A NaN distance is the one thing a minimum cannot order the way the sequential rule does: a camera matrix with an
+    infinite entry makes rays with NaN components; the cooperative scan notices and hands those rays to the sequential
+    scan.  Packed pixels agree with the oracle, NaNs sit in the same places (NaN payloads are the hardware's own)."""
+    rng = np.random.default_rng(3)
+    spheres, materials, camera = _sphere_field(rng, 1200)
+    width, height = 20, 11
+    ivp = list(camera.describe(width, height).inverse_view_projection[:])
+    ivp[1] = float("inf")  # x of the un-projected points: inf - inf along the way
+    pod = rt_amd.scene_from_arrays(spheres, [], materials, samples_per_pixel=3, max_bounces=5, inverse_view_projection=ivp)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=2)
+    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=2, flags=FORCE_STREAMED, want_rgb=True)
+    assert np.isnan(want_rgb).any()
+    same = (got_rgb.view(np.uint32) == want_rgb.view(np.uint32)) | (np.isnan(got_rgb) & np.isnan(want_rgb))
+    assert same.all() and np.array_equal(got_rgba, want_rgba) and stats["segments"] == want_stats["segments"]
 
 
 # ---- error behaviour of the boundary -----------------------------------------------------------------------------------------------
