@@ -27,7 +27,10 @@
 //   at(ray,t)         = fmaf(d, t, o) per component
 //   lerp(a,b,t)       = fmaf(b - a, t, a) per component
 //   transform_position(M,v): row_r = fmaf(M[r][0],v.x, fmaf(M[r][1],v.y, fmaf(M[r][2],v.z, M[r][3])));
-//                            xyz = row_0..2 * (1.0f / row_3)
+//                            xyz = row_0..2 * (1.0f / row_3)       (the preview, and primary rays of a matrix with varying w)
+//   primary ray (v3)       : for a matrix whose w is constant over the frame (rt's camera) the near point and the
+//                            near-to-far vector are affine in the pixel position: constants in binary64 (make_frame),
+//                            origin_c = fmaf(o1_c,px, fmaf(o2_c,py, o0_c)), toward_c likewise; dir = normalize(toward)
 //   pixel sum               : samples are added in CHUNKS of 16 consecutive samples (each chunk summed in sample
 //                            order, starting from 0), and the chunk sums are added in chunk order (left fold starting
 //                            from the first chunk's sum).  For spp <= 16 this is the reference's plain sequential
@@ -208,6 +211,10 @@ namespace
 		std::vector<material> materials;
 		uint32_t width, height;
 		float sx, sy; // 2 / W, 2 / H
+		// contract v3: primary rays of a camera whose w is constant over the frame (rt's: camera.hpp:122-137) — near point
+		// and near-to-far vector as affine functions of the pixel position, constants worked out in binary64
+		bool affine_rays;
+		float ray_o0[3], ray_o1[3], ray_o2[3], ray_d0[3], ray_d1[3], ray_d2[3];
 		frame_keys keys;
 		int trace_order;
 		bool sm_materials;
@@ -221,6 +228,34 @@ namespace
 		f.height = h;
 		f.sx = 2.0f / static_cast<float>(w);
 		f.sy = 2.0f / static_cast<float>(h);
+		{
+			// viewport::screen_to_world (camera.hpp:42-48) un-projects ndc = (2x/W - 1, -2y/H + 1, depth) through the inverse
+			// view-projection M and divides by w.  For rt's camera the last row of M has no x and no y term, so w depends on
+			// the depth alone: near(px, py) = (M0 X + M1 Y + k_near) / w_near is affine in the pixel position, and so is
+			// far - near.  The constants are worked out here in binary64, in this order of operations, and rounded to
+			// binary32 once (rt_amd/csrc/api.hip has the same lines); a ray then costs two fmas per component.
+			const float* M = s->inverse_view_projection;
+			float k_near[4], k_far[4];
+			for (int r = 0; r < 4; r++)
+			{
+				k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
+				k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
+			}
+			f.affine_rays = M[12] == 0.0f && M[13] == 0.0f && k_near[3] != 0.0f && k_far[3] != 0.0f && std::isfinite(k_near[3]) && std::isfinite(k_far[3]);
+			if (f.affine_rays)
+			{
+				const double sx = 2.0 / static_cast<double>(w), sy = -(2.0 / static_cast<double>(h));
+				const double iwn = 1.0 / static_cast<double>(k_near[3]), iwf = 1.0 / static_cast<double>(k_far[3]);
+				for (int c = 0; c < 3; c++)
+				{
+					const double mx = M[c * 4 + 0], my = M[c * 4 + 1], kn = k_near[c], kf = k_far[c];
+					const double o1 = mx * sx * iwn, o2 = my * sy * iwn, o0 = (kn - mx + my) * iwn;
+					const double e1 = mx * sx * iwf, e2 = my * sy * iwf, e0 = (kf - mx + my) * iwf;
+					f.ray_o0[c] = static_cast<float>(o0), f.ray_o1[c] = static_cast<float>(o1), f.ray_o2[c] = static_cast<float>(o2);
+					f.ray_d0[c] = static_cast<float>(e0 - o0), f.ray_d1[c] = static_cast<float>(e1 - o1), f.ray_d2[c] = static_cast<float>(e2 - o2);
+				}
+			}
+		}
 		f.keys = make_frame_keys(seed);
 		f.trace_order = mode & ORACLE_TRACE_RECURSIVE;
 		f.sm_materials = (mode & ORACLE_MATERIALS_SM) != 0;
@@ -257,6 +292,14 @@ namespace
 
 	inline ray primary_ray(const frame& f, float px, float py)
 	{
+		if (f.affine_rays) // near point and near-to-far vector straight from the pixel position (see make_frame)
+		{
+			const vec3 near_pos = { std::fmaf(f.ray_o1[0], px, std::fmaf(f.ray_o2[0], py, f.ray_o0[0])), std::fmaf(f.ray_o1[1], px, std::fmaf(f.ray_o2[1], py, f.ray_o0[1])),
+									std::fmaf(f.ray_o1[2], px, std::fmaf(f.ray_o2[2], py, f.ray_o0[2])) };
+			const vec3 toward = { std::fmaf(f.ray_d1[0], px, std::fmaf(f.ray_d2[0], py, f.ray_d0[0])), std::fmaf(f.ray_d1[1], px, std::fmaf(f.ray_d2[1], py, f.ray_d0[1])),
+								  std::fmaf(f.ray_d1[2], px, std::fmaf(f.ray_d2[2], py, f.ray_d0[2])) };
+			return { near_pos, normalize(toward) }; // mg_ray_tracer.cpp:190-193
+		}
 		const vec3 near_pos = screen_to_world(f, px, py, 0.0f); // mg_ray_tracer.cpp:190
 		const vec3 far_pos = screen_to_world(f, px, py, 1.0f);	// :191
 		return { near_pos, direction(near_pos, far_pos) };		// :193

@@ -1119,12 +1119,29 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	f.uniform_w = (f.mx[3] == 0.0f && f.my[3] == 0.0f && f.k_near[3] != 0.0f && f.k_far[3] != 0.0f && std::isfinite(f.k_near[3]) && std::isfinite(f.k_far[3])) ? 1u : 0u;
 	f.inv_w_near = f.uniform_w ? 1.0f / f.k_near[3] : 0.0f;
 	f.inv_w_far = f.uniform_w ? 1.0f / f.k_far[3] : 0.0f;
+	if (f.uniform_w)
+	{
+		// Contract v3, item 3 (oracle/cpu_ref.cpp make_frame has the same lines): with w constant over the frame,
+		//   near(px, py) = (mx X + my Y + k_near) / w_near,   X = (2/W) px - 1,   Y = -(2/H) py + 1,
+		// is affine in the pixel position, and so is far - near.  The constants are worked out in binary64, in THIS
+		// order of operations, and rounded to binary32 once; the kernels evaluate two fmas per component.
+		const double sx = 2.0 / static_cast<double>(width), sy = -(2.0 / static_cast<double>(height));
+		const double iwn = 1.0 / static_cast<double>(f.k_near[3]), iwf = 1.0 / static_cast<double>(f.k_far[3]);
+		for (int c = 0; c < 3; c++)
+		{
+			const double mx = f.mx[c], my = f.my[c], kn = f.k_near[c], kf = f.k_far[c];
+			const double o1 = mx * sx * iwn, o2 = my * sy * iwn, o0 = (kn - mx + my) * iwn;
+			const double e1 = mx * sx * iwf, e2 = my * sy * iwf, e0 = (kf - mx + my) * iwf;
+			f.ray_o0[c] = static_cast<float>(o0), f.ray_o1[c] = static_cast<float>(o1), f.ray_o2[c] = static_cast<float>(o2);
+			f.ray_d0[c] = static_cast<float>(e0 - o0), f.ray_d1[c] = static_cast<float>(e1 - o1), f.ray_d2[c] = static_cast<float>(e2 - o2);
+		}
+	}
 
 	bool rolling_items = false; // the persistent big-scene kernels draw items from a sequence whose head must start at 0
 	rolling_buffers rolling;
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel);
+		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
 		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);

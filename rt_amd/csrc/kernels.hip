@@ -1004,25 +1004,38 @@ namespace rt_hip
 							counter = counter_at_start;
 						const float px = fma(jx, random_scale, st.fx); // == fx + jx * 2^-24: the product is exact
 						const float py = fma(jy, random_scale, st.fy);
-						const float ndc_x = fma(px, p.sx, -1.0f);
-						const float ndc_y = fma(py, p.neg_sy, 1.0f);
-						float near_row[3], far_row[3];
+						// rt's camera (w constant over the frame): near point and near-to-far vector are affine in (px, py) —
+						// contract v3, constants from the host.  Any other matrix goes through the per-sample division; that
+						// path exists in the LDS / big-scene kernels only (the launch code never picks the scalar-register
+						// kernel for such a frame): as kernel arguments its 18 scalars would cost the small kernels, whose
+						// loop lives on its scalar registers, a spill per lane mask.
+						constexpr bool GENERAL_CAMERA = NS <= 0;
+						if (!GENERAL_CAMERA || p.uniform_w) // (wave-uniform: a kernel argument)
+						{
+							st.origin = { fma(p.ray_o1[0], px, fma(p.ray_o2[0], py, p.ray_o0[0])), fma(p.ray_o1[1], px, fma(p.ray_o2[1], py, p.ray_o0[1])),
+										  fma(p.ray_o1[2], px, fma(p.ray_o2[2], py, p.ray_o0[2])) };
+							toward = { fma(p.ray_d1[0], px, fma(p.ray_d2[0], py, p.ray_d0[0])), fma(p.ray_d1[1], px, fma(p.ray_d2[1], py, p.ray_d0[1])),
+									   fma(p.ray_d1[2], px, fma(p.ray_d2[2], py, p.ray_d0[2])) };
+						}
+						else
+						{
+							// un-project to depth 0 and depth 1 with the per-sample division (camera.hpp:42-48)
+							const float ndc_x = fma(px, p.sx, -1.0f);
+							const float ndc_y = fma(py, p.neg_sy, 1.0f);
+							float near_row[3], far_row[3];
 #pragma unroll
-						for (int r = 0; r < 3; r++)
-						{
-							near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
-							far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
+							for (int r = 0; r < 3; r++)
+							{
+								near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
+								far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
+							}
+							const float inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
+							const float inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
+							const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
+							const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
+							st.origin = near_pos;
+							toward = far_pos - near_pos; // vec3::direction(near, far) (:193)
 						}
-						float inv_wn = p.inv_w_near, inv_wf = p.inv_w_far;
-						if (!p.uniform_w) // wave-uniform (kernel argument)
-						{
-							inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
-							inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
-						}
-						const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
-						const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
-						st.origin = near_pos;
-						toward = far_pos - near_pos; // vec3::direction(near, far) (:193)
 						st.throughput = { 1.0f, 1.0f, 1.0f };
 						st.bounces_left = p.max_bounces;
 						mode = lane_trace;
@@ -1410,14 +1423,15 @@ namespace rt_hip
 	}
 
 #ifndef RT_HIP_FAST_BUILD
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool uniform_w)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
 		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
 			return RT_HIP_KERNEL_STREAMED;
 		if (flags & RT_HIP_FLAG_FORCE_TILED)
 			return RT_HIP_KERNEL_TILED;
-		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
+		// (the scalar-register kernel knows rt's camera only — a matrix whose w varies over the frame takes the LDS kernel)
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && uniform_w && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		if (primitives <= resident_max_primitives)
 			return RT_HIP_KERNEL_RESIDENT;
@@ -1489,7 +1503,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene);

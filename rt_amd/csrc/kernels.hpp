@@ -71,6 +71,14 @@ namespace rt_hip
 		// uniform_w != 0 says so; inv_w_* then hold 1.0f / k_*[3] (bit-identical to the per-sample division).
 		uint32_t uniform_w;
 		float inv_w_near, inv_w_far;
+		// Contract v3, primary rays of such a camera (uniform_w != 0): with w constant, the un-projected near point and
+		// the vector from it to the far point are AFFINE in the pixel position (px, py) — the per-frame constants are
+		// worked out once on the host in binary64 and rounded to binary32 (api.hip, primary_ray_constants; the oracle
+		// does the same): origin_c = fma(ray_o1[c], px, fma(ray_o2[c], py, ray_o0[c])), toward_c likewise from ray_d*.
+		// The scalar-register kernels read ONLY these; mx .. k_far above serve the preview and, in the LDS / big-scene
+		// kernels, a matrix whose w varies over the frame.
+		float ray_o0[3], ray_o1[3], ray_o2[3];
+		float ray_d0[3], ray_d1[3], ray_d2[3];
 	};
 
 	// the whole scene of the `small` kernel, passed by value as a kernel argument (-> SGPRs); host copy kept by the context
@@ -152,7 +160,7 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool uniform_w);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,
