@@ -644,11 +644,27 @@ def test_noise_statistics_at_1080p_match_independent_generators(tracer):
         pytest.skip("the mt19937 model of a 1080p x 16 spp frame wants a many-core host (the GPU boxes have 256 threads)")
     width, height = 1920, 1080
     scene = rt_amd.Scene.named("basic")
-    truth = tracer.render(scene.set_sampling(1024).describe(width, height), width, height, seed=99, want_rgb=True)[1].astype(np.float64)
+    import warnings
+
+    def sane(make, name):
+        """The radiance of this scene is <= 1.  One full-suite run in six of round 3 found float64 garbage in `truth` — bytes that
+        look like packed RGBA8 pixels, in an array no render writes to — and neither 400 rounds of tools/gpu_pageable_stress.py nor
+        three more full runs reproduced it.  This test is about random streams, not about that: a broken buffer is rendered
+        again, loudly."""
+        for attempt in range(2):
+            img = make()
+            wild = np.argwhere(~(np.abs(img) < 4.0).all(axis=-1))
+            if len(wild) == 0:
+                return img
+            warnings.warn(f"{name}: {len(wild)} pixels outside [0, 4) (attempt {attempt}); first at (y, x) = {wild[:8].tolist()}, values {img[tuple(wild[0])]}, "
+                          f"byte offset {int((wild[0][0] * width + wild[0][1]) * 3 * img.itemsize)}")
+        raise AssertionError(f"{name}: still broken after rendering it again")
+
+    truth = sane(lambda: tracer.render(scene.set_sampling(1024).describe(width, height), width, height, seed=99, want_rgb=True)[1].astype(np.float64), "truth")
     pod = scene.set_sampling(16).describe(width, height)
-    ours = tracer.render(pod, width, height, seed=5, want_rgb=True)[1].astype(np.float64)
-    _, model, _ = oracle.render_mt19937(pod, width, height, fixed_seed=77, want_rgb=True)
-    model = model.astype(np.float64)
+    ours = sane(lambda: tracer.render(pod, width, height, seed=5, want_rgb=True)[1].astype(np.float64), "ours")
+    model = sane(lambda: oracle.render_mt19937(pod, width, height, fixed_seed=77, want_rgb=True)[1].astype(np.float64), "model")
+    assert (np.abs(truth) < 4.0).all()  # (and nothing rendered later wrote into it)
 
     def noise(img):
         err = (img - truth)[..., 0]  # red channel: ground, sky and both spheres all show in it
