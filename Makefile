@@ -11,7 +11,7 @@ HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fa
 HOSTFLAGS:= -std=c++20 -O2 -fPIC -Wall -Wextra
 
 HIP_SRC  := rt_amd/csrc/kernels.hip rt_amd/csrc/api.hip
-HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp include/rt_hip.h
+HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp rt_amd/csrc/frame_group.hpp include/rt_hip.h
 HOST_SRC := rt_amd/host/host_capi.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
 HOST_HDR := $(wildcard rt_amd/host/*.hpp) rt_amd/host/host_capi.h rt_amd/host/named_colours.inc include/rt_hip.h
 

@@ -15,17 +15,21 @@ were uploaded during warm-up and are not re-sent while unchanged), kernel(s), fo
 de-interleave, and the transfer of the frame to the host.  `value` is that drop-in rate; the kernel-only rate (scene
 resident, frame left in HBM) is carried beside it as `kernel_only`.  The frame is fixed as N grows: scaling is STRONG.
 
-N > 1 under torchrun runs the step in TWO forms, one after the other, and says so in the line:
-  * `torch`   — torch.distributed.gather + rt_hip_assemble_device + a copy to a pinned host frame: building blocks that
-                every ROCm installation exercises;
-  * `library` — every process is one rank of the module's OWN renderer (rt_hip_create + rt_hip_join_ranks:
-                ncclCommInitRank; one ncclGather inside librt_hip.so; the root assembles straight into the page-locked
-                back buffer): the product path, and what `value` reports when it came up, produced the very frame the
-                `torch` form produced, and finished; otherwise `value` is the `torch` form's and `paths.library` says why.
-The ranks vote before anything collective is entered, the collective join has a deadline, and a watchdog turns a hang
-of the library form into the `torch` line instead of a lost run.  Every N > 1 line carries what RCCL reports about the
-communicator (`rccl`), every rank's own kernel time (`per_rank`) and the root's render / gather / assemble / copy split
-(`drop_in_breakdown`).
+N > 1 under torchrun runs the step in THREE forms, one after the other, and says so in the line (`paths`):
+  * `torch`        — torch.distributed.gather + rt_hip_assemble_device + a copy to a pinned host frame: building blocks
+                     that every ROCm installation exercises;
+  * `shared_frame` — every process is one rank of a FRAME GROUP (rt_hip_create + rt_hip_join_frame_group): the caller's
+                     back buffer is a shared mapping every rank process maps and page-locks, and every rank's kernel
+                     stores its stripes straight into it over its own PCIe link — no data-path collective, no RCCL;
+  * `library`      — every process is one rank of the module's gathering renderer (rt_hip_create + rt_hip_join_ranks:
+                     ncclCommInitRank; one ncclGather inside librt_hip.so; the root assembles straight into its
+                     page-locked back buffer).
+The last two are the product path (rt_hip_render delivers the finished frame into rank 0's host buffer).  `value` is the
+faster of those that came up, produced the very frame the `torch` form produced, and finished (`value_from` names it);
+if neither did, `value` is the `torch` form's and `paths` says why.  The ranks vote before anything collective is
+entered, the joins have deadlines, and a watchdog turns a hang of either form into the best line so far instead of a
+lost run.  Every N > 1 line carries what the transport reports about itself (`rccl`), every rank's own kernel time
+(`per_rank`) and rank 0's split of a step (`drop_in_breakdown`).
 
 The `roofline` object prices the render kernel against the FP32 vector-ALU peak — the bound SURVEY.md §8d identifies for
 this path (a 3-sphere scene is ~100 bytes; the only compulsory HBM traffic is the 4 B/pixel frame) — from the kernel's
@@ -244,6 +248,8 @@ def main() -> None:
             },
             "roofline": roofline,
         }
+        if form == "shared_frame":
+            line["config"]["frame_buffer"] = "rank 0's back buffer is a shared mapping (MAP_SHARED) that every rank's process maps and page-locks: what the multi-process form of a direct frame needs (INTEGRATION.md)"
         line.update(more)
         return line
 
@@ -374,85 +380,152 @@ def main() -> None:
         torch_member0 = tracers[(args.steps - 1) % in_flight].stats()
         torch_transport = "torch.distributed.gather (backend nccl = RCCL)" if args.backend == "nccl" else "torch.distributed.gather over gloo (rehearsal: stripes staged through host memory)"
         paths = {"torch": {"ms_per_step": round(torch_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / torch_elapsed / 1e6, 1), "transport": torch_transport, "per_rank": spread(torch_kernels) if in_flight == 1 else None}}
-        chosen = "torch"
-        elapsed, per_rank_kernel_ms, member0, transport = torch_elapsed, torch_kernels, torch_member0, torch_transport
-        stats = torch_member0
 
-        # -- form 2: the module's own renderer, one rank per process --
-        if args.gather == "library" and args.backend == "nccl":
-            deadline = args.library_deadline_s or (120.0 + 50.0 * torch_form_seconds)
+        # -- the module's own renderers, one rank per process: each form under a watchdog, validated against the torch form's frame --
+        results = {"torch": (torch_elapsed, torch_kernels, torch_member0, torch_transport, {})}  # form -> (elapsed, per-rank kernel ms, rank 0's stats, transport text, extra keys of the line)
+        state = {"chosen": "torch"}
+
+        def line_for(form):
+            form_elapsed, form_kernels, form_member0, form_transport, form_extras = results[form]
+            more = dict(form_extras, paths=paths, value_from=form, per_rank=spread(form_kernels) if in_flight == 1 else None)
+            if "rccl" not in more and args.backend == "nccl":
+                more["rccl"] = {"ranks": world, "devices": None, "transport": form_transport, "source": "torch.distributed's process group (the module's own communicator was not used)"}
+            return build_line(form, form_elapsed, form_kernels, form_member0, f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {form_transport}", more)
+
+        def guarded(form, deadline, body):
+            """body() under a watchdog: a form that does not come back (a collective that never completes cannot be
+            cancelled) costs the run nothing but that form — rank 0 prints the best line so far and every process ends."""
             finished = threading.Event()
-            torch_line_ready = {}
 
             def watchdog():
                 if finished.wait(deadline):
                     return
-                # the library form hung (a collective that never completes cannot be cancelled): the run still reports
-                if rank == 0 and torch_line_ready:
-                    line = torch_line_ready["make"](f"hung: no result within {deadline:.0f} s; the processes were ended by the benchmark's watchdog")
-                    print(json.dumps(line), flush=True)
+                paths[form] = {"status": f"hung: no result within {deadline:.0f} s; the processes were ended by the benchmark's watchdog"}
+                if rank == 0:
+                    print(json.dumps(line_for(state["chosen"])), flush=True)
                 sys.stdout.flush()
                 os._exit(0)
 
-            def make_torch_line(why):
-                paths["library"] = {"status": why}
-                more = {"paths": paths, "value_from": "torch", "per_rank": spread(torch_kernels), "rccl": {"ranks": world, "devices": None, "transport": torch_transport, "source": "torch.distributed's process group (the module's own communicator did not finish)"}}
-                return build_line("torch", torch_elapsed, torch_kernels, torch_member0, f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {torch_transport}", more)
+            threading.Thread(target=watchdog, daemon=True).start()
+            try:
+                return body()
+            finally:
+                finished.set()
 
-            library = {"status": "not attempted"}
-            rank_tracer, reason = distributed.negotiate_rank_renderer(
-                create=lambda: rt_amd.HipRayTracer(device=device),
-                join=lambda t, unique: t.join_ranks(rank, world, unique, timeout_ms=int(min(deadline, 120.0) * 1e3)),
-                make_id=rt_amd.unique_id,
-                vote_device=vote_device,
-                log=lambda message: print(message, file=sys.stderr, flush=True),
-            )
-            if rank_tracer is None:
-                library = {"status": f"not available: {reason}"}
-            else:
+        def adopt(form):  # a drop-in form always outranks the torch form; among drop-in forms the faster one is `value`
+            if state["chosen"] == "torch" or results[form][0] < results[state["chosen"]][0]:
+                state["chosen"] = form
+
+        def measure_drop_in(form, form_tracer, back_buffer, transport_text, rccl_source):
+            """Validate (the very frame the torch form delivered), settle, time; fills paths[form] and results[form]."""
+            render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+            phase_samples: list[dict] = []
+
+            def form_step():  # collective and blocking: rank 0 returns with the frame in its back buffer
+                if os.environ.get("RT_BENCH_TEST_HANG") == form or os.environ.get("RT_BENCH_TEST_HANG") == "1":  # tests/test_bench_contract.py: the watchdog's rehearsal
+                    time.sleep(3600)
+                return form_tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
+
+            form_step()
+            same = True
+            if rank == 0:
+                same = bool(np.array_equal(np.asarray(back_buffer).view(np.int32), host_frame.numpy()))
+            if not distributed.all_agree(same, vote_device):
+                paths[form] = {"status": "frame differs from the torch form's frame: not used"}
+                return
+
+            def measured_step():
+                s = form_step()
+                phase_samples.append(form_tracer.phases())
+                return s
+
+            settle(own_share)  # (bringing a form up leaves the GPU idle for a moment: clocks up again first)
+            form_elapsed, form_kernels = timed(measured_step, lambda s: s["render_ms"] if form != "shared_frame" else form_tracer.member_stats(rank)["render_ms"])
+            phase_samples[:] = phase_samples[-args.steps :]
+            infos = [None] * world
+            dist.all_gather_object(infos, form_tracer.comm_info())
+            phases = mean_phases(phase_samples)
+            form_extras = {
+                "drop_in_breakdown": dict({"kernel_ms": round(form_kernels[0], 4), "wall_ms": round(form_elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases}),
+                "rccl": {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": rccl_source},
+            }
+            paths[form] = {"status": "ok", "ms_per_step": round(form_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / form_elapsed / 1e6, 1), "per_rank": spread(form_kernels)}
+            results[form] = (form_elapsed, form_kernels, form_tracer.member_stats(0), transport_text, form_extras)  # (member 0 = rank 0's share: the launch the roofline prices)
+            adopt(form)
+
+        deadline = args.library_deadline_s or (120.0 + 50.0 * torch_form_seconds)
+        log = lambda message: print(message, file=sys.stderr, flush=True)  # noqa: E731
+
+        # -- form 2: rt_hip_join_frame_group — every rank's kernel stores its stripes straight into ONE shared back buffer;
+        #    no RCCL in the data path (so it also runs in the gloo rehearsal, where the ranks share a device) --
+        if args.gather == "library":
+
+            def shared_form():
+                names = [None]
+                if rank == 0:
+                    names[0] = f"rt_hip_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFFFF:08x}"
+                dist.broadcast_object_list(names, src=0)
+                frame_path = f"/dev/shm/{names[0]}_frame"
+                shared = None
+                try:
+                    if rank == 0:  # the "caller's back buffer": a shared mapping every rank process maps
+                        np.zeros((args.height, args.width), dtype=np.uint32).tofile(frame_path)
+                    dist.barrier()
+                    group_tracer, reason = distributed.negotiate_rank_renderer(
+                        create=lambda: rt_amd.HipRayTracer(device=device),
+                        join=lambda t, unique: t.join_frame_group(rank, world, f"/{names[0]}_group", timeout_ms=int(min(deadline, 120.0) * 1e3)),
+                        make_id=lambda: bytes(128),  # (nothing to hand out: the group's name is all the ranks need)
+                        vote_device=vote_device,
+                        log=log,
+                    )
+                    if group_tracer is None:
+                        paths["shared_frame"] = {"status": f"not available: {reason}"}
+                        return
+                    tracers.append(group_tracer)
+                    shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+                    measure_drop_in("shared_frame", group_tracer, shared,
+                                    "inside librt_hip.so: rt_hip_create + rt_hip_join_frame_group; every rank's kernel stores its stripes straight into ONE shared, page-locked back buffer over its own PCIe link; no data-path collective (two shared-memory counters per frame); torch.distributed only hands out the name, votes and keeps time",
+                                    "no communicator: rt_hip_join_frame_group's control block in POSIX shared memory (this transport does not use RCCL)")
+                except rt_amd.RtHipError as e:  # a frame group reports a broken frame on every rank alike
+                    paths["shared_frame"] = {"status": f"failed: {e}"}
+                finally:
+                    dist.barrier()
+                    if rank == 0:
+                        try:
+                            os.unlink(frame_path)
+                        except OSError:
+                            pass
+
+            guarded("shared_frame", deadline, shared_form)
+
+        # -- form 3: rt_hip_join_ranks — ncclCommInitRank, one ncclGather to rank 0, assemble into rank 0's page-locked back buffer --
+        if args.gather == "library" and args.backend == "nccl":
+
+            def library_form():
+                rank_tracer, reason = distributed.negotiate_rank_renderer(
+                    create=lambda: rt_amd.HipRayTracer(device=device),
+                    join=lambda t, unique: t.join_ranks(rank, world, unique, timeout_ms=int(min(deadline, 120.0) * 1e3)),
+                    make_id=rt_amd.unique_id,
+                    vote_device=vote_device,
+                    log=log,
+                )
+                if rank_tracer is None:
+                    paths["library"] = {"status": f"not available: {reason}"}
+                    return
                 tracers.append(rank_tracer)
                 back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
-                render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
-                phase_samples: list[dict] = []
+                measure_drop_in("library", rank_tracer, back_buffer,
+                                "inside librt_hip.so: rt_hip_create + rt_hip_join_ranks (ncclCommInitRank) + one ncclGather to rank 0; torch.distributed only hands out the id, votes and keeps time",
+                                "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on every rank's communicator")
 
-                def library_step():  # collective and blocking: rank 0 returns with the frame in its back buffer
-                    if os.environ.get("RT_BENCH_TEST_HANG"):  # tests/test_bench_contract.py: the watchdog's rehearsal
-                        time.sleep(3600)
-                    return rank_tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
-
-                torch_line_ready["make"] = make_torch_line
-                threading.Thread(target=watchdog, daemon=True).start()
-                # validation: the very frame the torch form delivered
-                library_step()
-                same = True
-                if rank == 0:
-                    same = bool(np.array_equal(back_buffer.view(np.int32), host_frame.numpy()))
-                if not distributed.all_agree(same, vote_device):
-                    library = {"status": "frame differs from the torch form's frame: not used"}
-                else:
-
-                    def measured_step():
-                        s = library_step()
-                        phase_samples.append(rank_tracer.phases())
-                        return s
-
-                    settle(own_share)  # (bringing the communicator up left the GPU idle for a second or two: clocks up again first)
-                    lib_elapsed, lib_kernels = timed(measured_step, lambda s: s["render_ms"])
-                    phase_samples[:] = phase_samples[-args.steps :]
-                    infos = [None] * world
-                    dist.all_gather_object(infos, rank_tracer.comm_info())
-                    library = {"status": "ok", "ms_per_step": round(lib_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / lib_elapsed / 1e6, 1), "per_rank": spread(lib_kernels)}
-                    chosen = "library"
-                    elapsed, per_rank_kernel_ms, member0 = lib_elapsed, lib_kernels, rank_tracer.stats()
-                    stats = member0
-                    transport = "inside librt_hip.so: rt_hip_create + rt_hip_join_ranks (ncclCommInitRank) + one ncclGather to rank 0; torch.distributed only hands out the id, votes and keeps time"
-                    phases = mean_phases(phase_samples)
-                    extras["drop_in_breakdown"] = dict({"kernel_ms": round(lib_kernels[0], 4), "wall_ms": round(lib_elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases})
-                    extras["rccl"] = {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on every rank's communicator"}
-                finished.set()
-            paths["library"] = library
+            paths["library"] = {"status": "not attempted"}
+            guarded("library", deadline, library_form)
         elif args.gather == "library":
-            paths["library"] = {"status": "not attempted: --backend gloo rehearses the torch form only"}
+            paths["library"] = {"status": "not attempted: --backend gloo rehearses the torch and the shared-frame forms only"}
+        chosen = state["chosen"]
+        elapsed, per_rank_kernel_ms, member0, transport, chosen_extras = results[chosen]
+        stats = member0
+        extras.update(chosen_extras)
         extras["paths"] = paths
         extras["value_from"] = chosen
         extras["per_rank"] = spread(per_rank_kernel_ms) if in_flight == 1 else None

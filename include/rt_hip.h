@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 4u
+#define RT_HIP_ABI_VERSION 5u
 
 typedef enum rt_hip_status
 {
@@ -277,13 +277,38 @@ rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int
  */
 rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES], uint32_t timeout_ms);
 
+/*
+ * ONE PROCESS PER GPU WITHOUT AN EXCHANGE STEP — what RT_HIP_MULTI_DIRECT_FRAME is for one process, for `torchrun`-style
+ * jobs.  The caller's back buffer is a SHARED mapping (shm_open / memfd + mmap(MAP_SHARED)) that every rank's process
+ * maps; each rank page-locks its own mapping and its kernel stores the rank's stripes straight into their image rows,
+ * over that GPU's own PCIe link, while the frame is still being traced.  No RCCL, no stripe buffers, no assemble, no
+ * copy: the gathered form puts 7/8 of an 8-GPU frame through rank 0's single PCIe link AFTER the tracing (0.14 ms for a
+ * 1080p frame whose tracing takes 0.36 ms per rank).  The ranks meet in a control block in POSIX shared memory
+ * (rt_amd/csrc/frame_group.hpp) twice per frame — "everybody is in the call", "everybody's stripes are in place".
+ *   rt_hip_join_frame_group(ctx, rank, world, name, timeout_ms) on a context from rt_hip_create, on every process,
+ *       collectively.  `name` is a fresh shm_open name ("/rt_hip_<something unique>") all ranks were handed by any means;
+ *       rank 0 creates the object, the others wait for it; when all have mapped it the name is removed again.  Waits at
+ *       most timeout_ms (0 = RT_HIP_JOIN_TIMEOUT_MS, else 120 000) -> RT_HIP_TIMEOUT; the context then stays a plain one.
+ *   rt_hip_render(ctx, scene, pixels, ...) on EVERY rank, with the same scene, size, seed and flags and with `pixels` =
+ *       that process's mapping of the one shared buffer (the library checks all of this: a rank called with other
+ *       arguments, or whose `pixels` is not the memory rank 0 renders into, fails the frame on every rank).  Returns on
+ *       every rank when the WHOLE frame is in the buffer.  RT_HIP_FLAG_PERSISTENT_FRAME is implied; rgb_f32 must be NULL.
+ *       `stats` / rt_hip_stats_fetch give the whole frame (counts summed over the ranks, the slowest rank's kernel time),
+ *       rt_hip_member_stats(ctx, r, ..) / rt_hip_member_device(ctx, r, ..) rank r's share and device, for any r < world.
+ * A rank that fails, leaves (rt_hip_destroy) or stays away longer than RT_HIP_GROUP_DEADLINE_MS (default 120 000) breaks
+ * the group: every rank's current and later rt_hip_render returns an error naming the rank and the reason; the renderer
+ * is then destroyed and made anew.  Nothing in the reference corresponds (it is one process, one thread pool).
+ */
+rt_hip_status rt_hip_join_frame_group(rt_hip_ctx* ctx, int rank, int world, const char* name, uint32_t timeout_ms);
+
 /* How the stripes of a multi-GPU frame reach the root: what a context was created with (and what a bench line should say). */
 enum
 {
 	RT_HIP_TRANSPORT_NONE		  = 0, /* one GPU: nothing to exchange */
 	RT_HIP_TRANSPORT_RCCL_GATHER  = 1, /* one ncclGather to rank 0 */
 	RT_HIP_TRANSPORT_PEER_COPY	  = 2, /* RT_HIP_MULTI_PEER_COPY: hipMemcpyPeerAsync into the root */
-	RT_HIP_TRANSPORT_DIRECT_FRAME = 3  /* RT_HIP_MULTI_DIRECT_FRAME took effect in the most recent frame: no exchange at all */
+	RT_HIP_TRANSPORT_DIRECT_FRAME = 3, /* RT_HIP_MULTI_DIRECT_FRAME took effect in the most recent frame: no exchange at all */
+	RT_HIP_TRANSPORT_SHARED_FRAME = 4  /* rt_hip_join_frame_group: every rank's process stores into ONE shared back buffer */
 };
 /* What member `member` of the context talks through, as RCCL itself reports it (rccl.h: ncclCommCount, ncclCommUserRank,
  * ncclCommCuDevice): the communicator's size, this member's rank in it, and the device the communicator lives on.  Contexts

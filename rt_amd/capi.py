@@ -16,7 +16,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 
-RT_HIP_ABI_VERSION = 4
+RT_HIP_ABI_VERSION = 5
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
@@ -29,7 +29,7 @@ RT_HIP_FLAG_STATS = 1 << 7
 RT_HIP_MULTI_PEER_COPY = 1 << 0
 RT_HIP_MULTI_DIRECT_FRAME = 1 << 1
 RT_HIP_TRANSPORT_NONE, RT_HIP_TRANSPORT_RCCL_GATHER, RT_HIP_TRANSPORT_PEER_COPY, RT_HIP_TRANSPORT_DIRECT_FRAME = 0, 1, 2, 3
-TRANSPORT_NAMES = {0: "none", 1: "rccl_gather", 2: "peer_copy", 3: "direct_frame"}
+TRANSPORT_NAMES = {0: "none", 1: "rccl_gather", 2: "peer_copy", 3: "direct_frame", 4: "shared_frame"}
 KERNEL_NAMES = {0: "none", 1: "resident", 2: "tiled", 3: "small", 4: "preview", 5: "streamed"}
 
 STATUS_NAMES = {
@@ -140,6 +140,7 @@ RT_HIP_SYMBOLS = [
     ("rt_hip_unique_id", C.c_int, [C.c_char * 128]),
     ("rt_hip_create_rank", C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_char * 128]),
     ("rt_hip_join_ranks", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char * 128, C.c_uint32]),
+    ("rt_hip_join_frame_group", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.c_uint32]),
     ("rt_hip_comm_info", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), c_u32_p]),
     ("rt_hip_member_count", C.c_int, [C.c_void_p, C.POINTER(C.c_int)]),
     ("rt_hip_member_device", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),

@@ -5,6 +5,7 @@
 // turned into RT_HIP_RUNTIME_ERROR + a message (the reference's render() is noexcept, src/renderer.hpp:11).
 #include "../../include/rt_hip.h"
 #include "contract.hpp"
+#include "frame_group.hpp"
 #include "kernels.hpp"
 
 #include <rccl/rccl.h>
@@ -170,6 +171,8 @@ struct rt_hip_ctx
 	device_buffer stripes_rgba, stripes_rgb;   // this member's compact stripe buffers (the gather's send side)
 	device_buffer gathered_rgba, gathered_rgb; // root: n x padded stripes, rank order (the gather's receive side)
 	hipEvent_t stripes_ready = nullptr;		   // recorded on `stream` after this member's launch (peer copies wait for it)
+	// ---- or: one rank of a renderer whose ranks are processes that all map the caller's back buffer (rt_hip_join_frame_group)
+	std::unique_ptr<frame_group> group;
 
 	// staging for the drop-in rt_hip_render()
 	device_buffer frame_rgba, frame_rgb;
@@ -462,7 +465,7 @@ extern "C" rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world,
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_ranks: NULL argument");
 	if (world < 1 || world > 4096 || rank < 0 || rank >= world)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_ranks: invalid rank %d of %d", rank, world);
-	if (ctx->multi)
+	if (ctx->multi || ctx->group)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_ranks: the context already belongs to a multi-GPU renderer");
 	if (!timeout_ms)
 	{
@@ -539,6 +542,50 @@ extern "C" rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, in
 	return ok();
 }
 
+extern "C" rt_hip_status rt_hip_join_frame_group(rt_hip_ctx* ctx, int rank, int world, const char* name, uint32_t timeout_ms)
+{
+	if (!ctx || !name)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_frame_group: NULL argument");
+	if (world < 1 || world > static_cast<int>(frame_group_max_ranks) || rank < 0 || rank >= world)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_frame_group: invalid rank %d of %d (at most %u ranks)", rank, world, frame_group_max_ranks);
+	if (ctx->multi || ctx->group)
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_join_frame_group: the context already belongs to a multi-GPU renderer");
+	if (!timeout_ms)
+	{
+		timeout_ms = 120000u;
+		if (const char* knob = std::getenv("RT_HIP_JOIN_TIMEOUT_MS"))
+		{
+			const long v = std::strtol(knob, nullptr, 10);
+			if (v > 0 && v < 0x7FFFFFFFl)
+				timeout_ms = static_cast<uint32_t>(v);
+		}
+	}
+	try
+	{
+		auto group = std::make_unique<frame_group>();
+		if (const char* knob = std::getenv("RT_HIP_GROUP_DEADLINE_MS"))
+		{
+			const long v = std::strtol(knob, nullptr, 10);
+			if (v > 0 && v < 0x7FFFFFFFl)
+				group->deadline_ms = static_cast<uint32_t>(v);
+		}
+		const frame_group::outcome joined = group->join(name, static_cast<uint32_t>(rank), static_cast<uint32_t>(world), timeout_ms);
+		if (joined == frame_group::outcome::timed_out)
+			return fail(RT_HIP_TIMEOUT, "rt_hip_join_frame_group: %s", group->error.c_str());
+		if (joined != frame_group::outcome::ok)
+			return fail(joined == frame_group::outcome::failed && !group->block ? RT_HIP_INVALID_ARGUMENT : RT_HIP_RUNTIME_ERROR, "rt_hip_join_frame_group: %s", group->error.c_str());
+		group->block->ranks[rank].device = ctx->device;
+		ctx->group = std::move(group);
+		ctx->world = static_cast<uint32_t>(world);
+		ctx->first_rank = static_cast<uint32_t>(rank);
+		return ok();
+	}
+	catch (const std::exception& e)
+	{
+		return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_join_frame_group: %s", e.what());
+	}
+}
+
 extern "C" rt_hip_status rt_hip_comm_info(const rt_hip_ctx* ctx, int member, int* out_ranks, int* out_rank, int* out_device, uint32_t* out_transport)
 {
 	if (!ctx || member < 0 || member > static_cast<int>(ctx->peers.size()))
@@ -550,6 +597,8 @@ extern "C" rt_hip_status rt_hip_comm_info(const rt_hip_ctx* ctx, int member, int
 		transport = ctx->peer_copy ? RT_HIP_TRANSPORT_PEER_COPY : RT_HIP_TRANSPORT_RCCL_GATHER;
 	if (ctx->multi && ctx->phases.transport == RT_HIP_TRANSPORT_DIRECT_FRAME)
 		transport = RT_HIP_TRANSPORT_DIRECT_FRAME;
+	if (ctx->group)
+		transport = RT_HIP_TRANSPORT_SHARED_FRAME;
 	if (static_cast<size_t>(member) < ctx->comms.size() && ctx->comms[static_cast<size_t>(member)])
 	{
 		// what RCCL itself says about the communicator this member talks through
@@ -589,6 +638,11 @@ namespace
 
 extern "C" rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device)
 {
+	if (ctx && ctx->group && out_device && rank >= 0 && rank < static_cast<int>(ctx->world))
+	{
+		*out_device = ctx->group->block->ranks[rank].device; // (the ordinal as that rank's process counts its devices)
+		return ok();
+	}
 	const rt_hip_ctx* member = member_of(const_cast<rt_hip_ctx*>(ctx), rank);
 	if (!member || !out_device)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_member_device: invalid argument");
@@ -600,6 +654,7 @@ extern "C" void rt_hip_destroy(rt_hip_ctx* ctx)
 {
 	if (!ctx)
 		return;
+	ctx->group.reset(); // leaves the group: the other ranks stop waiting for this one at once
 	// communicators first (they hold resources on every member's device), then the members, then the root
 	for (const ncclComm_t comm : ctx->comms)
 		if (comm)
@@ -1250,6 +1305,40 @@ namespace
 	}
 }
 
+namespace
+{
+	rt_hip_stats stats_of_group_rank(const rt_hip_ctx* ctx, uint32_t rank)
+	{
+		const frame_group_rank& line = ctx->group->block->ranks[rank];
+		rt_hip_stats out{};
+		out.primary_samples = line.primary_samples;
+		out.segments = line.segments;
+		out.sphere_tests = line.sphere_tests;
+		out.plane_tests = line.plane_tests;
+		out.render_ms = line.render_ms;
+		out.upload_ms = line.upload_ms;
+		out.kernel_variant = line.kernel_variant;
+		return out;
+	}
+
+	// whole-frame counters of a frame group: counts summed over the ranks, times the slowest rank's
+	void sum_group_stats(const rt_hip_ctx* ctx, rt_hip_stats* out)
+	{
+		for (uint32_t r = 0; r < ctx->world; r++)
+		{
+			if (r == ctx->first_rank)
+				continue;
+			const rt_hip_stats other = stats_of_group_rank(ctx, r);
+			out->primary_samples += other.primary_samples;
+			out->segments += other.segments;
+			out->sphere_tests += other.sphere_tests;
+			out->plane_tests += other.plane_tests;
+			out->render_ms = std::max(out->render_ms, other.render_ms);
+			out->upload_ms = std::max(out->upload_ms, other.upload_ms);
+		}
+	}
+}
+
 extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats)
 {
 	if (!ctx || !out_stats)
@@ -1257,6 +1346,8 @@ extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_s
 	if (const rt_hip_status st = fetch_member_stats(ctx))
 		return st;
 	*out_stats = ctx->stats;
+	if (ctx->group) // the other ranks' shares are in the group's block (valid between two frames)
+		sum_group_stats(ctx, out_stats);
 	// several GPUs: the frame's counts are the sum over the members' shares, its kernel time the slowest member's
 	for (rt_hip_ctx* member : ctx->peers)
 	{
@@ -1276,6 +1367,11 @@ extern "C" rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_s
 
 extern "C" rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_stats)
 {
+	if (ctx && ctx->group && out_stats && rank >= 0 && rank < static_cast<int>(ctx->world))
+	{
+		*out_stats = stats_of_group_rank(ctx, static_cast<uint32_t>(rank)); // (that rank's share of the most recent frame that kept stats)
+		return ok();
+	}
 	rt_hip_ctx* member = member_of(ctx, rank);
 	if (!member || !out_stats)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_member_stats: invalid argument");
@@ -1296,7 +1392,7 @@ namespace
 	// any other buffer (or no flag) first drops the old registration — before anything else touches host memory.
 	// A buffer whose page-lock was refused (registered by somebody else, not lockable) is remembered and not tried again
 	// while it keeps arriving: neither the mbind nor the failing hipHostRegister is repeated every frame.
-	void track_frame_buffer(rt_hip_ctx* ctx, uint32_t* pixels, size_t bytes, bool pin)
+	void track_frame_buffer(rt_hip_ctx* ctx, uint32_t* pixels, size_t bytes, bool pin, bool may_move_pages = true)
 	{
 		if (ctx->pinned_frame && (!pin || ctx->pinned_frame != pixels || ctx->pinned_bytes != bytes))
 			unpin_frame(ctx);
@@ -1307,7 +1403,8 @@ namespace
 		}
 		if (pin && !ctx->pinned_frame && !ctx->refused_frame)
 		{
-			place_on_node(pixels, bytes, ctx->numa_node); // before the pages are locked where they are
+			if (may_move_pages)
+				place_on_node(pixels, bytes, ctx->numa_node); // before the pages are locked where they are
 			const hipError_t e = hipHostRegister(pixels, bytes, hipHostRegisterMapped | (ctx->direct_frame ? hipHostRegisterPortable : 0u));
 			if (debug_frame())
 				std::fprintf(stderr, "rt_hip: device %d registered back buffer %p (%zu bytes): %s\n", ctx->device, static_cast<void*>(pixels), bytes, hipGetErrorString(e));
@@ -1609,6 +1706,141 @@ namespace
 	}
 }
 
+namespace
+{
+	// rt_hip_render on a context that joined a frame group: this rank's stripes, straight into the back buffer all ranks map
+	rt_hip_status render_group(rt_hip_ctx* ctx,
+							   const rt_hip_scene* scene,
+							   uint32_t* pixels_rgba8888,
+							   uint32_t width,
+							   uint32_t height,
+							   uint64_t seed,
+							   uint32_t flags,
+							   float* rgb_f32,
+							   rt_hip_stats* stats,
+							   std::chrono::steady_clock::time_point entered)
+	{
+		frame_group& group = *ctx->group;
+		const uint32_t rank = group.rank, world = group.world;
+		const bool keep_stats = stats || (flags & RT_HIP_FLAG_STATS);
+		// Whatever goes wrong on this rank alone breaks the group: the other ranks are (or will be) waiting for this one.
+		const auto give_up = [&](rt_hip_status status) -> rt_hip_status
+		{
+			group.break_group("rank %u: %s", rank, g_last_error.c_str());
+			return status;
+		};
+		const auto group_failed = [&](frame_group::outcome o) -> rt_hip_status
+		{
+			return fail(o == frame_group::outcome::timed_out ? RT_HIP_TIMEOUT : RT_HIP_RUNTIME_ERROR, "rt_hip_render: %s", group.error.c_str());
+		};
+		if (group.is_broken())
+			return fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: the frame group is broken: %s", group.why_broken().c_str());
+		if (!pixels_rgba8888)
+			return give_up(fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: every rank of a frame group passes its mapping of the shared pixel buffer"));
+		if (rgb_f32)
+			return give_up(fail(RT_HIP_UNSUPPORTED, "rt_hip_render: the float mean does not travel through a shared frame (use rt_hip_join_ranks)"));
+
+		// this rank's own preparations: the scene (normally one fingerprint pass and one comparison), the page-lock
+		const auto scene_t0 = std::chrono::steady_clock::now();
+		scene_request request;
+		if (const rt_hip_status st = open_request(request, scene))
+			return give_up(st);
+		ctx->phases = rt_hip_phases{};
+		ctx->phases.transport = RT_HIP_TRANSPORT_SHARED_FRAME;
+		if (const rt_hip_status st = make_resident(ctx, request))
+			return give_up(st);
+		ctx->stats.upload_ms = static_cast<float>(seconds_since(scene_t0) * 1e3);
+		const size_t frame_bytes = static_cast<size_t>(width) * height * sizeof(uint32_t);
+		const void* const locked_before = ctx->pinned_frame;
+		const size_t bytes_before = ctx->pinned_bytes;
+		// (only rank 0 asks for the pages to be moved to its GPU's NUMA node: they are everybody's)
+		track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, true, rank == 0);
+		uint32_t* mapped_frame = nullptr;
+		if (ctx->pinned_frame == pixels_rgba8888)
+		{
+			void* view = nullptr;
+			if (hipHostGetDevicePointer(&view, pixels_rgba8888, 0) == hipSuccess && view)
+				mapped_frame = static_cast<uint32_t*>(view);
+			else
+				(void)hipGetLastError();
+		}
+		if (!mapped_frame)
+			return give_up(fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: rank %u could not page-lock and map the shared pixel buffer %p (%zu bytes)", rank, static_cast<void*>(pixels_rgba8888), frame_bytes));
+		frame_group_rank& mine = group.block->ranks[rank];
+		mine.new_buffer = (locked_before != ctx->pinned_frame || bytes_before != ctx->pinned_bytes) ? 1u : 0u;
+
+		// 1. everybody is in the call, with the same arguments (rank 0's are the reference)
+		// (the columns' fingerprint does not cover what changes per frame: camera and bounce limit are folded in here)
+		uint64_t print = request.print ^ (0x9E3779B97F4A7C15ull * (scene->max_bounces + 1ull));
+		for (const float m : scene->inverse_view_projection)
+		{
+			uint32_t bits;
+			std::memcpy(&bits, &m, sizeof(bits));
+			print = (print ^ bits) * 0x100000001B3ull;
+		}
+		const frame_group_call call = { width, height, flags & render_flag_mask, scene->samples_per_pixel, seed, print };
+		if (rank == 0)
+			group.block->call = call;
+		if (const frame_group::outcome o = group.enter_frame(); o != frame_group::outcome::ok)
+			return group_failed(o);
+		if (rank != 0 && !same_call(group.block->call, call))
+		{
+			const frame_group_call& theirs = group.block->call;
+			return give_up(fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: rank %u was called with %ux%u, %u spp, seed %llu, flags 0x%x, scene %016llx; rank 0 with %ux%u, %u spp, seed %llu, flags 0x%x, scene %016llx",
+								rank, width, height, call.samples_per_pixel, static_cast<unsigned long long>(seed), call.flags, static_cast<unsigned long long>(call.scene_fingerprint),
+								theirs.width, theirs.height, theirs.samples_per_pixel, static_cast<unsigned long long>(theirs.seed), theirs.flags, static_cast<unsigned long long>(theirs.scene_fingerprint)));
+		}
+		// 2. a buffer somebody sees for the first time: are the ranks' mappings one memory?
+		if (group.any_new_buffer())
+			if (const frame_group::outcome o = group.check_buffer(pixels_rgba8888); o != frame_group::outcome::ok)
+				return group_failed(o);
+
+		// 3. this rank's stripes, stored straight into their image rows (system-scope stores over this GPU's own PCIe link)
+		const rt_hip_partition part = { rank, world, RT_HIP_DEFAULT_STRIPE_ROWS };
+		const rt_hip_status launched = render_device(ctx, width, height, seed, flags & render_flag_mask, &part, mapped_frame, nullptr, ctx->stream, true, keep_stats);
+		const auto issued = std::chrono::steady_clock::now();
+		// (from here on the device may be storing into the shared buffer: no return before the stream has drained)
+		const hipError_t drained = hipStreamSynchronize(ctx->stream);
+		if (launched != RT_HIP_OK)
+			return give_up(launched);
+		if (drained != hipSuccess)
+			return give_up(fail(RT_HIP_RUNTIME_ERROR, "hipStreamSynchronize failed: %s", hipGetErrorString(drained)));
+		if (keep_stats)
+		{
+			if (const rt_hip_status st = fetch_member_stats(ctx))
+				return give_up(st);
+		}
+		else
+		{
+			ctx->stats.segments = ctx->stats.sphere_tests = ctx->stats.plane_tests = 0;
+			ctx->stats.render_ms = 0.0f;
+		}
+		mine.primary_samples = ctx->stats.primary_samples;
+		mine.segments = ctx->stats.segments;
+		mine.sphere_tests = ctx->stats.sphere_tests;
+		mine.plane_tests = ctx->stats.plane_tests;
+		mine.render_ms = ctx->stats.render_ms;
+		mine.upload_ms = ctx->stats.upload_ms;
+		mine.kernel_variant = ctx->stats.kernel_variant;
+
+		// 4. the frame is complete when every rank's stripes are in place
+		const auto own_done = std::chrono::steady_clock::now();
+		if (const frame_group::outcome o = group.finish_frame(); o != frame_group::outcome::ok)
+			return group_failed(o);
+		ctx->stats.readback_ms = 0.0f;
+		ctx->phases.render_ms = ctx->stats.render_ms;
+		ctx->phases.gather_ms = static_cast<float>(seconds_since(own_done) * 1e3); // waiting for the slowest rank (host clock)
+		ctx->phases.host_issue_ms = static_cast<float>(std::chrono::duration<double>(issued - entered).count() * 1e3);
+		ctx->phases.host_wait_ms = static_cast<float>(seconds_since(issued) * 1e3);
+		if (stats)
+		{
+			*stats = ctx->stats;
+			sum_group_stats(ctx, stats);
+		}
+		return ok();
+	}
+}
+
 extern "C" void rt_hip_forget_frame(rt_hip_ctx* ctx)
 {
 	if (!ctx)
@@ -1640,7 +1872,7 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 									   rt_hip_stats* stats)
 {
 	const auto entered = std::chrono::steady_clock::now();
-	if (!ctx || !scene || (!pixels_rgba8888 && !(ctx->multi && ctx->first_rank != 0)))
+	if (!ctx || !scene || (!pixels_rgba8888 && !(ctx->multi && ctx->first_rank != 0) && !ctx->group))
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: NULL argument");
 	if (!width || !height)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render: empty frame %ux%u", width, height);
@@ -1652,6 +1884,8 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 	try
 	{
 		RT_HIP_TRY(hipSetDevice(ctx->device));
+		if (ctx->group)
+			return render_group(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats, entered);
 		if (pixels_rgba8888)
 			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0);
 		if (ctx->multi)

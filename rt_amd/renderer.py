@@ -91,6 +91,14 @@ class HipRayTracer:
         check(self._lib.rt_hip_join_ranks(self._ctx, rank, world, (C.c_char * 128).from_buffer_copy(unique_id), timeout_ms))
         self.rank, self.world = rank, world
 
+    def join_frame_group(self, rank: int, world: int, name: str, timeout_ms: int = 0) -> None:
+        """rt_hip_join_frame_group: one process per GPU without an exchange step.  On a context made by plain
+        ``HipRayTracer(device)``, collectively; afterwards EVERY rank calls ``render(..., out=<its mapping of the one shared
+        uint32[H, W] buffer>)`` and every call returns when the whole frame is in that buffer.  `name`: a fresh shm_open name
+        ("/rt_hip_...") all ranks were handed.  Raises RtHipError (RT_HIP_TIMEOUT after `timeout_ms`)."""
+        check(self._lib.rt_hip_join_frame_group(self._ctx, rank, world, name.encode(), timeout_ms))
+        self.rank, self.world, self.shared_frame = rank, world, True
+
     def comm_info(self, member: int = 0) -> dict:
         """What RCCL reports about the communicator member `member` talks through (rt_hip_comm_info)."""
         ranks, rank, device, transport = C.c_int(), C.c_int(), C.c_int(), C.c_uint32()
@@ -126,7 +134,7 @@ class HipRayTracer:
         want_stats = stats
         stats = RtHipStats()
         stats_arg = C.byref(stats) if want_stats else None
-        if self.rank != 0:  # a rank whose rank 0 lives in another process renders and sends; it has no frame of its own
+        if self.rank != 0 and not getattr(self, "shared_frame", False):  # a rank whose rank 0 lives in another process renders and sends; it has no frame of its own
             rgb = np.empty((height, width, 3), dtype=np.float32) if want_rgb else None
             check(self._lib.rt_hip_render(self._ctx, C.byref(scene), None, width, height, seed, flags, rgb.ctypes.data if rgb is not None else None, stats_arg))
             return None, None, stats.as_dict() if want_stats else {}

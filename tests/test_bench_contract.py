@@ -107,14 +107,15 @@ def test_one_rank_under_torchrun_takes_the_library_rank_path():
         port = s.getsockname()[1]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
     line = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--spp", "32", "--cpu-baseline-seconds", "0"], launcher=launcher)
-    assert line["n_gpus"] == 1 and "ncclCommInitRank" in line["config"]["parallelism"]
+    assert line["n_gpus"] == 1 and ("ncclCommInitRank" in line["config"]["parallelism"] or "rt_hip_join_frame_group" in line["config"]["parallelism"])
     assert line["value"] == pytest.approx(1920 * 1080 * 32 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
     assert 0 < line["roofline"]["frac"] < 1
-    # both forms ran; the library form came up, reproduced the torch form's frame and is what `value` reports
-    assert line["value_from"] == "library" and line["paths"]["library"]["status"] == "ok" and line["paths"]["torch"]["value"] > 0
-    assert line["paths"]["library"]["ms_per_step"] == pytest.approx(line["ms_per_step"])
-    # what RCCL itself says about the communicator, every rank's kernel time, the root's split of a step
-    assert line["rccl"] == {"ranks": 1, "devices": [0], "rank_of_process": [0], "transport": "rccl_gather", "source": line["rccl"]["source"]}
+    # all three forms ran; both product forms came up and reproduced the torch form's frame; the faster one is `value`
+    assert line["paths"]["library"]["status"] == "ok" and line["paths"]["shared_frame"]["status"] == "ok" and line["paths"]["torch"]["value"] > 0
+    assert line["value_from"] == min(("library", "shared_frame"), key=lambda form: line["paths"][form]["ms_per_step"])
+    assert line["paths"][line["value_from"]]["ms_per_step"] == pytest.approx(line["ms_per_step"])
+    # what the transport says about itself, every rank's kernel time, the root's split of a step
+    assert line["rccl"] == {"ranks": 1, "devices": [0], "rank_of_process": [0], "transport": {"library": "rccl_gather", "shared_frame": "shared_frame"}[line["value_from"]], "source": line["rccl"]["source"]}
     assert len(line["per_rank"]["kernel_ms"]) == 1 and 0 < line["per_rank"]["kernel_ms_max"] <= line["ms_per_step"]
     split = line["drop_in_breakdown"]
     assert {"render_ms", "gather_ms", "assemble_ms", "copy_ms", "host_issue_ms", "host_wait_ms", "wall_ms"} <= set(split)
@@ -122,19 +123,41 @@ def test_one_rank_under_torchrun_takes_the_library_rank_path():
 
 
 @pytest.mark.gpu
-def test_a_library_form_that_hangs_still_yields_the_torch_line():
-    """The watchdog of the N > 1 flow: if the module's own renderer never finishes (RT_BENCH_TEST_HANG stalls the library
-    form in this test), the benchmark prints the torch form's line — marked as such — and ends, instead of losing the run."""
+@pytest.mark.parametrize("stalled, survivor", [("1", "torch"), ("library", "shared_frame")])
+def test_a_product_form_that_hangs_still_yields_the_best_line_so_far(stalled, survivor):
+    """The watchdog of the N > 1 flow: if one of the module's own renderers never finishes (RT_BENCH_TEST_HANG stalls the
+    named form — "1": whichever runs first), the benchmark prints the best line it has so far — the torch form's, or the
+    shared-frame form's when only the gathering renderer hung — and ends, instead of losing the run."""
     import socket
 
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    os.environ["RT_BENCH_TEST_HANG"] = "1"
+    os.environ["RT_BENCH_TEST_HANG"] = stalled
     try:
         line = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0", "--library-deadline-s", "5"], launcher=launcher)
     finally:
         del os.environ["RT_BENCH_TEST_HANG"]
-    assert line["value_from"] == "torch" and "hung" in line["paths"]["library"]["status"]
+    assert line["value_from"] == survivor and "hung" in line["paths"]["shared_frame" if stalled == "1" else "library"]["status"]
     assert line["value"] == pytest.approx(1920 * 1080 * 16 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    assert line["paths"][survivor]["ms_per_step"] == pytest.approx(line["ms_per_step"])
+
+
+@pytest.mark.gpu
+def test_four_processes_on_one_device_rehearse_the_shared_frame_form():
+    """`torchrun --nproc-per-node 4 bench.py --gpus 4 --backend gloo`: four rank processes on the box's one GPU.  The torch
+    form stages the stripes through host memory (gloo); the frame group needs no RCCL and runs as it would on four GPUs —
+    same protocol, same stores into one shared back buffer, validated against the torch form's frame."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    line = run_bench(["--gpus", "4", "--steps", "3", "--warmup", "1", "--spp", "32", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
+    assert line["n_gpus"] == 4 and line["value_from"] == "shared_frame" and line["paths"]["shared_frame"]["status"] == "ok"
+    assert "gloo" in line["paths"]["library"]["status"] and line["paths"]["torch"]["value"] > 0
+    assert line["rccl"] == {"ranks": 4, "devices": [0, 0, 0, 0], "rank_of_process": [0, 1, 2, 3], "transport": "shared_frame", "source": line["rccl"]["source"]}
+    assert len(line["per_rank"]["kernel_ms"]) == 4 and "frame_buffer" in line["config"]
+    assert line["drop_in_breakdown"]["transport"] == "shared_frame"
