@@ -89,10 +89,10 @@ def test_two_ranks_on_one_gpu_rehearse_the_multi_gpu_step():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port)]
-    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--cpu-baseline-seconds", "0"], launcher=launcher)
+    line = run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--spp", "16", "--backend", "gloo", "--gather", "torch", "--cpu-baseline-seconds", "0"], launcher=launcher)
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
     assert "one process per GPU" in line["config"]["parallelism"] and line["config"]["frames_in_flight"] == 1
-    assert line["value_from"] == "torch" and "gloo" in line["paths"]["library"]["status"]
+    assert line["value_from"] == "torch" and set(line["paths"]) == {"torch"}
     assert len(line["per_rank"]["kernel_ms"]) == 2 and line["paths"]["torch"]["ms_per_step"] == pytest.approx(line["ms_per_step"])
 
 
