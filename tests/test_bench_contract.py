@@ -160,4 +160,5 @@ def test_four_processes_on_one_device_rehearse_the_shared_frame_form():
     assert "gloo" in line["paths"]["library"]["status"] and line["paths"]["torch"]["value"] > 0
     assert line["rccl"] == {"ranks": 4, "devices": [0, 0, 0, 0], "rank_of_process": [0, 1, 2, 3], "transport": "shared_frame", "source": line["rccl"]["source"]}
     assert len(line["per_rank"]["kernel_ms"]) == 4 and "frame_buffer" in line["config"]
-    assert line["drop_in_breakdown"]["transport"] == "shared_frame"
+    split = line["drop_in_breakdown"]
+    assert split["render_ms"] > 0 and split["assemble_ms"] == 0 and split["copy_ms"] == 0  # nothing is exchanged, nothing copied
