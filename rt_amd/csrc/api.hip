@@ -186,6 +186,9 @@ struct rt_hip_ctx
 	void* refused_frame = nullptr; // a buffer whose page-lock failed: not tried again while it keeps arriving
 	size_t refused_bytes = 0;
 
+	const void* asked_pointer = nullptr; // rt_hip_render_device: the last output pointer and whether it is host memory
+	bool asked_pointer_is_host = false;
+
 	// KAT scratch
 	device_buffer kat_in, kat_out;
 
@@ -248,6 +251,63 @@ namespace
 		(void)syscall(SYS_mbind, begin, end - begin, mpol_preferred, mask, 1024ul + 1ul, mpol_mf_move);
 #else
 		(void)ptr, (void)bytes, (void)node;
+#endif
+	}
+
+	// The same for a frame whose row stripes are stored by DIFFERENT GPUs (direct-frame members, the ranks of a frame
+	// group): every whole page goes to the node of the GPU that owns the stripe the page begins in.  On the two-socket
+	// GPU hosts half of the GPUs hang off each socket; with the whole frame on one node the other half store across
+	// the socket interconnect (+23..37 % kernel time for a GPU that stores a whole frame into far memory,
+	// profiles/r03/shared_frame_numa.txt).  One move_pages(2) call with a target node per page: no memory policy is
+	// installed and no mapping is split.  Pages have to be present to be moved, so they are touched first (a read per
+	// page: the content stays); pages that are page-locked or mapped by another process stay where they are.  Best effort.
+	void place_stripes(void* ptr, size_t bytes, uint32_t width, uint32_t height, uint32_t stripe_rows, const std::vector<int>& node_of_rank)
+	{
+#ifdef SYS_move_pages
+		if (!ptr || !bytes || node_of_rank.empty() || !width || !height || !stripe_rows)
+			return;
+		if (const char* knob = std::getenv("RT_HIP_NUMA_MOVE"))
+			if (knob[0] == '0' && knob[1] == '\0')
+				return;
+		bool any = false;
+		for (const int node : node_of_rank)
+			any = any || (node >= 0 && node < 1024);
+		if (!any)
+			return;
+		const long page = sysconf(_SC_PAGESIZE);
+		if (page <= 0)
+			return;
+		const uintptr_t mask_low = static_cast<uintptr_t>(page - 1);
+		const uintptr_t base = reinterpret_cast<uintptr_t>(ptr);
+		const uintptr_t begin = (base + mask_low) & ~mask_low;
+		const uintptr_t end = (base + bytes) & ~mask_low;
+		if (end <= begin)
+			return;
+		const size_t count = (end - begin) / static_cast<size_t>(page);
+		std::vector<void*> pages;
+		std::vector<int> nodes;
+		pages.reserve(count);
+		nodes.reserve(count);
+		const size_t row_bytes = static_cast<size_t>(width) * sizeof(uint32_t);
+		volatile unsigned char sink = 0;
+		for (size_t i = 0; i < count; i++)
+		{
+			const uintptr_t address = begin + i * static_cast<size_t>(page);
+			const size_t row = std::min<size_t>((address - base) / row_bytes, height - 1u);
+			const int node = node_of_rank[(row / stripe_rows) % node_of_rank.size()];
+			if (node < 0 || node >= 1024)
+				continue;
+			sink = static_cast<unsigned char>(sink + *reinterpret_cast<const volatile unsigned char*>(address)); // present from here on
+			pages.push_back(reinterpret_cast<void*>(address));
+			nodes.push_back(node);
+		}
+		if (pages.empty())
+			return;
+		std::vector<int> status(pages.size(), 0);
+		constexpr int mpol_mf_move = 2;
+		(void)syscall(SYS_move_pages, 0, static_cast<unsigned long>(pages.size()), pages.data(), nodes.data(), status.data(), mpol_mf_move);
+#else
+		(void)ptr, (void)bytes, (void)width, (void)height, (void)stripe_rows, (void)node_of_rank;
 #endif
 	}
 
@@ -325,6 +385,13 @@ extern "C" rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device)
 	ctx->device = device;
 	ctx->compute_units = props.multiProcessorCount > 0 ? static_cast<uint32_t>(props.multiProcessorCount) : 256u;
 	ctx->numa_node = numa_node_of(device);
+	if (const char* knob = std::getenv("RT_HIP_NUMA_NODE")) // (tests and odd hosts: say which node the back buffer should live on)
+	{
+		char* end = nullptr;
+		const long v = std::strtol(knob, &end, 10);
+		if (end != knob && v >= -1 && v < 1024)
+			ctx->numa_node = static_cast<int>(v);
+	}
 	hipError_t e = ctx->counters.reserve(sizeof(device_counters));
 	if (e == hipSuccess)
 		e = hipEventCreate(&ctx->render_begin);
@@ -575,6 +642,7 @@ extern "C" rt_hip_status rt_hip_join_frame_group(rt_hip_ctx* ctx, int rank, int 
 		if (joined != frame_group::outcome::ok)
 			return fail(joined == frame_group::outcome::failed && !group->block ? RT_HIP_INVALID_ARGUMENT : RT_HIP_RUNTIME_ERROR, "rt_hip_join_frame_group: %s", group->error.c_str());
 		group->block->ranks[rank].device = ctx->device;
+		group->block->ranks[rank].numa_node = ctx->numa_node;
 		ctx->group = std::move(group);
 		ctx->world = static_cast<uint32_t>(world);
 		ctx->first_rank = static_cast<uint32_t>(rank);
@@ -1091,7 +1159,23 @@ extern "C" rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
 
 namespace
 {
-	rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers, bool keep_stats);
+	rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers, bool keep_stats, bool host_frame);
+
+	// Is this "device" pointer page-locked host memory (a caller may hand rt_hip_render_device the device view of its own
+	// registered buffer)?  Asked once per pointer: the answer of the last one is kept.
+	bool is_host_memory(rt_hip_ctx* ctx, const void* pointer)
+	{
+		if (pointer != ctx->asked_pointer)
+		{
+			hipPointerAttribute_t attributes{};
+			const hipError_t e = hipPointerGetAttributes(&attributes, pointer);
+			if (e != hipSuccess)
+				(void)hipGetLastError();
+			ctx->asked_pointer = pointer;
+			ctx->asked_pointer_is_host = e == hipSuccess && attributes.type == hipMemoryTypeHost;
+		}
+		return ctx->asked_pointer_is_host;
+	}
 }
 
 extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
@@ -1104,7 +1188,7 @@ extern "C" rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 											  float* d_rgb_f32,
 											  void* stream)
 {
-	return render_device(ctx, width, height, seed, flags, part, d_rgba8, d_rgb_f32, stream, false, true);
+	return render_device(ctx, width, height, seed, flags, part, d_rgba8, d_rgb_f32, stream, false, true, ctx && d_rgba8 && is_host_memory(ctx, d_rgba8));
 }
 
 namespace
@@ -1113,7 +1197,8 @@ namespace
 // (several GPUs rendering into one host frame); otherwise the rank's compact stripe buffer, as the public call documents.
 // keep_stats: bracket the launch with timing events, zero the work counters before it and read them back after it.  Without
 // it NOTHING but the kernel is enqueued (the plug-in's call: rt_hip_render with stats == NULL).
-rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers, bool keep_stats)
+// host_frame: d_rgba8 is page-locked host memory (the mapped back buffer): the tiles are cut for PCIe writes (choose_queue).
+rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, uint64_t seed, uint32_t flags, const rt_hip_partition* part, uint32_t* d_rgba8, float* d_rgb_f32, void* stream, bool whole_frame_buffers, bool keep_stats, bool host_frame)
 {
 	if (!ctx || !d_rgba8)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: NULL argument");
@@ -1199,7 +1284,7 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
-		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene);
+		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame);
 		// small scenes: a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
 		const uint64_t slot_bytes = big_scene ? 0u : 4ull * (static_cast<uint64_t>(queue.chunks) << queue.pixels_log2) * 12u;
 		if (slot_bytes > 48u * 1024u)
@@ -1234,9 +1319,9 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	if (flags & RT_HIP_FLAG_PREVIEW)
 		launch_preview(f, ctx->scene, d_rgba8, d_rgb_f32, counters, s);
 	else if (flags & RT_HIP_FLAG_FAST)
-		variant = launch_render_fast(f, ctx->scene, ctx->small, flags, d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
+		variant = launch_render_fast(f, ctx->scene, ctx->small, flags | (host_frame ? launch_flag_host_frame : 0u), d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
 	else
-		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags, d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
+		variant = launch_render(f, ctx->scene, (flags & RT_HIP_FLAG_SM_MATERIALS) ? ctx->small_sm : ctx->small, flags | (host_frame ? launch_flag_host_frame : 0u), d_rgba8, d_rgb_f32, counters, rolling, ctx->compute_units, ctx->cache, s);
 	RT_HIP_TRY(hipGetLastError());
 	ctx->launched = true;
 	ctx->last_stream = s;
@@ -1392,7 +1477,9 @@ namespace
 	// any other buffer (or no flag) first drops the old registration — before anything else touches host memory.
 	// A buffer whose page-lock was refused (registered by somebody else, not lockable) is remembered and not tried again
 	// while it keeps arriving: neither the mbind nor the failing hipHostRegister is repeated every frame.
-	void track_frame_buffer(rt_hip_ctx* ctx, uint32_t* pixels, size_t bytes, bool pin, bool may_move_pages = true)
+	// `stripe_nodes` (with the frame's shape): place the row stripes on their owners' nodes instead of the whole buffer on
+	// this context's (place_stripes).
+	void track_frame_buffer(rt_hip_ctx* ctx, uint32_t* pixels, size_t bytes, bool pin, bool may_move_pages = true, const std::vector<int>* stripe_nodes = nullptr, uint32_t width = 0, uint32_t height = 0)
 	{
 		if (ctx->pinned_frame && (!pin || ctx->pinned_frame != pixels || ctx->pinned_bytes != bytes))
 			unpin_frame(ctx);
@@ -1403,8 +1490,10 @@ namespace
 		}
 		if (pin && !ctx->pinned_frame && !ctx->refused_frame)
 		{
-			if (may_move_pages)
-				place_on_node(pixels, bytes, ctx->numa_node); // before the pages are locked where they are
+			if (may_move_pages && stripe_nodes)
+				place_stripes(pixels, bytes, width, height, RT_HIP_DEFAULT_STRIPE_ROWS, *stripe_nodes); // before the pages are locked where they are
+			else if (may_move_pages)
+				place_on_node(pixels, bytes, ctx->numa_node);
 			const hipError_t e = hipHostRegister(pixels, bytes, hipHostRegisterMapped | (ctx->direct_frame ? hipHostRegisterPortable : 0u));
 			if (debug_frame())
 				std::fprintf(stderr, "rt_hip: device %d registered back buffer %p (%zu bytes): %s\n", ctx->device, static_cast<void*>(pixels), bytes, hipGetErrorString(e));
@@ -1551,7 +1640,7 @@ namespace
 				{
 					rt_hip_ctx* member = member_of(root, r);
 					const rt_hip_partition part = { static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
-					if (const rt_hip_status st = render_device(member, width, height, seed, render_flags, &part, views[static_cast<size_t>(r)], nullptr, member->stream, true, keep_stats))
+					if (const rt_hip_status st = render_device(member, width, height, seed, render_flags, &part, views[static_cast<size_t>(r)], nullptr, member->stream, true, keep_stats, true))
 						return st;
 				}
 				const auto issued = std::chrono::steady_clock::now();
@@ -1609,7 +1698,7 @@ namespace
 			const rt_hip_partition part = { root->first_rank + static_cast<uint32_t>(r), world, RT_HIP_DEFAULT_STRIPE_ROWS };
 			const bool direct = root_direct && r == 0;
 			uint32_t* const target = direct ? mapped_frame : member->stripes_rgba.as<uint32_t>();
-			if (const rt_hip_status st = render_device(member, width, height, seed, render_flags, &part, target, rgb_f32 ? member->stripes_rgb.as<float>() : nullptr, member->stream, direct, keep_stats))
+			if (const rt_hip_status st = render_device(member, width, height, seed, render_flags, &part, target, rgb_f32 ? member->stripes_rgb.as<float>() : nullptr, member->stream, direct, keep_stats, direct))
 				return st;
 			if (root->peer_copy && r)
 				RT_HIP_TRY(hipEventRecord(member->stripes_ready, member->stream));
@@ -1751,23 +1840,12 @@ namespace
 			return give_up(st);
 		ctx->stats.upload_ms = static_cast<float>(seconds_since(scene_t0) * 1e3);
 		const size_t frame_bytes = static_cast<size_t>(width) * height * sizeof(uint32_t);
-		const void* const locked_before = ctx->pinned_frame;
-		const size_t bytes_before = ctx->pinned_bytes;
-		// (only rank 0 asks for the pages to be moved to its GPU's NUMA node: they are everybody's)
-		track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, true, rank == 0);
-		uint32_t* mapped_frame = nullptr;
-		if (ctx->pinned_frame == pixels_rgba8888)
-		{
-			void* view = nullptr;
-			if (hipHostGetDevicePointer(&view, pixels_rgba8888, 0) == hipSuccess && view)
-				mapped_frame = static_cast<uint32_t*>(view);
-			else
-				(void)hipGetLastError();
-		}
-		if (!mapped_frame)
-			return give_up(fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: rank %u could not page-lock and map the shared pixel buffer %p (%zu bytes)", rank, static_cast<void*>(pixels_rgba8888), frame_bytes));
+		// a buffer this rank has not seen before: the old page-lock goes now, the new one comes when the group has looked at it
+		const bool new_buffer = ctx->pinned_frame != pixels_rgba8888 || ctx->pinned_bytes != frame_bytes;
+		if (new_buffer)
+			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, false);
 		frame_group_rank& mine = group.block->ranks[rank];
-		mine.new_buffer = (locked_before != ctx->pinned_frame || bytes_before != ctx->pinned_bytes) ? 1u : 0u;
+		mine.new_buffer = new_buffer ? 1u : 0u;
 
 		// 1. everybody is in the call, with the same arguments (rank 0's are the reference)
 		// (the columns' fingerprint does not cover what changes per frame: camera and bounce limit are folded in here)
@@ -1790,14 +1868,38 @@ namespace
 								rank, width, height, call.samples_per_pixel, static_cast<unsigned long long>(seed), call.flags, static_cast<unsigned long long>(call.scene_fingerprint),
 								theirs.width, theirs.height, theirs.samples_per_pixel, static_cast<unsigned long long>(theirs.seed), theirs.flags, static_cast<unsigned long long>(theirs.scene_fingerprint)));
 		}
-		// 2. a buffer somebody sees for the first time: are the ranks' mappings one memory?
+		// 2. a buffer somebody sees for the first time.  While nobody has page-locked it yet (and only rank 0's process has
+		//    touched it: its caller clears the frame, src/main.cpp:318) rank 0 moves every stripe's pages to the host NUMA node
+		//    of the GPU that will store into them; then the group checks that the ranks' mappings are one memory.
 		if (group.any_new_buffer())
+		{
+			if (rank == 0 && new_buffer)
+			{
+				std::vector<int> nodes(world, -1);
+				for (uint32_t r = 0; r < world; r++)
+					nodes[r] = group.block->ranks[r].numa_node;
+				place_stripes(pixels_rgba8888, frame_bytes, width, height, RT_HIP_DEFAULT_STRIPE_ROWS, nodes);
+			}
 			if (const frame_group::outcome o = group.check_buffer(pixels_rgba8888); o != frame_group::outcome::ok)
 				return group_failed(o);
+		}
+		if (new_buffer)
+			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, true, false); // (the pages are where they should be: lock them there)
+		uint32_t* mapped_frame = nullptr;
+		if (ctx->pinned_frame == pixels_rgba8888)
+		{
+			void* view = nullptr;
+			if (hipHostGetDevicePointer(&view, pixels_rgba8888, 0) == hipSuccess && view)
+				mapped_frame = static_cast<uint32_t*>(view);
+			else
+				(void)hipGetLastError();
+		}
+		if (!mapped_frame)
+			return give_up(fail(RT_HIP_RUNTIME_ERROR, "rt_hip_render: rank %u could not page-lock and map the shared pixel buffer %p (%zu bytes)", rank, static_cast<void*>(pixels_rgba8888), frame_bytes));
 
 		// 3. this rank's stripes, stored straight into their image rows (system-scope stores over this GPU's own PCIe link)
 		const rt_hip_partition part = { rank, world, RT_HIP_DEFAULT_STRIPE_ROWS };
-		const rt_hip_status launched = render_device(ctx, width, height, seed, flags & render_flag_mask, &part, mapped_frame, nullptr, ctx->stream, true, keep_stats);
+		const rt_hip_status launched = render_device(ctx, width, height, seed, flags & render_flag_mask, &part, mapped_frame, nullptr, ctx->stream, true, keep_stats, true);
 		const auto issued = std::chrono::steady_clock::now();
 		// (from here on the device may be storing into the shared buffer: no return before the stream has drained)
 		const hipError_t drained = hipStreamSynchronize(ctx->stream);
@@ -1886,7 +1988,14 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		RT_HIP_TRY(hipSetDevice(ctx->device));
 		if (ctx->group)
 			return render_group(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats, entered);
-		if (pixels_rgba8888)
+		if (pixels_rgba8888 && ctx->multi && ctx->direct_frame && ctx->peers.size() + 1 == ctx->world)
+		{
+			std::vector<int> nodes(1, ctx->numa_node); // every member stores its own stripes: each stripe on its member's node
+			for (const rt_hip_ctx* member : ctx->peers)
+				nodes.push_back(member->numa_node);
+			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0, true, &nodes, width, height);
+		}
+		else if (pixels_rgba8888)
 			track_frame_buffer(ctx, pixels_rgba8888, frame_bytes, (flags & RT_HIP_FLAG_PERSISTENT_FRAME) != 0);
 		if (ctx->multi)
 			return render_multi(ctx, scene, pixels_rgba8888, width, height, seed, flags, rgb_f32, stats, entered);
@@ -1922,7 +2031,7 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		}
 		if (rgb_f32)
 			RT_HIP_TRY(ctx->frame_rgb.reserve(pixels * 3 * sizeof(float)));
-		if (const rt_hip_status st = render_device(ctx, width, height, seed, flags & render_flag_mask, nullptr, d_frame, rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, ctx->stream, false, keep_stats))
+		if (const rt_hip_status st = render_device(ctx, width, height, seed, flags & render_flag_mask, nullptr, d_frame, rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, ctx->stream, false, keep_stats, mapped))
 			return st;
 		// from here on the device may be storing into the caller's buffers: no return before the stream has drained
 		hipError_t e = hipSuccess;

@@ -54,6 +54,7 @@ namespace rt_hip
 	{
 		int32_t device;
 		int32_t pid;
+		int32_t numa_node;	 // host NUMA node that rank's GPU hangs off (-1: unknown)
 		uint32_t new_buffer; // this frame's pixel buffer was page-locked in this call (not seen before)
 		uint32_t kernel_variant;
 		uint64_t primary_samples, segments, sphere_tests, plane_tests;

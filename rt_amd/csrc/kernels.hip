@@ -48,6 +48,7 @@
 #include "../../include/rt_hip.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 // waves per SIMD the kernel variants are compiled for (register budget = 512 / waves): measured, see render_queue
 #ifndef RT_HIP_WAVES_FEW
@@ -1442,7 +1443,7 @@ namespace rt_hip
 		return samples_per_pixel >= 32u ? RT_HIP_KERNEL_STREAMED : RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame)
 	{
 		queue_params q{};
 		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk; // K chunks per pixel
@@ -1471,6 +1472,36 @@ namespace rt_hip
 		}
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+		if (host_frame && !big_scene)
+		{
+			// The finished pixels of a tile leave the wave as one store per tile, a row fragment of tile_w pixels per tile
+			// row; into page-locked host memory every fragment is a PCIe write.  Fragments of 8 and 16 bytes (2 x 2, 4 x 4,
+			// 4 x 2 tiles) cost nothing in HBM and a lot over PCIe as soon as there are many of them per microsecond — a 1/8
+			// share of the headline frame took 0.60 ms as 2 x 2 tiles against 0.35 ms into HBM, 0.37 ms as 4 x 1; config 2's
+			// whole frame 1.36 ms into memory of the other socket as 8 x 4, 0.86 ms as 16 x 2 — and so does memory on the far
+			// socket (profiles/r03/tile_shapes.txt).  So: rows as wide as the tile allows, up to 64 bytes.  One exception,
+			// where the launch has waves to spare: 256-spp frames of headline size take 16 pixels as 8 x 2 instead of 8 as
+			// 8 x 1 (half as many store instructions: as fast as the frame left in HBM whichever socket the memory is on).
+			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
+			if (pixels_log2 == 3u && (q.chunks << 4u) <= 256u && (pixels >> 4u) >= 49152u)
+			{
+				q.pixels_log2 = pixels_log2 = 4u;
+				q.tile_w_log2 = 3u;
+			}
+			else
+				q.tile_w_log2 = std::min(pixels_log2, 4u);
+		}
+#ifdef RT_HIP_QUEUE_KNOBS
+		// experiment builds only (tools/gpu_tile_shapes.py): tile size and width from the environment, per launch
+		if (!big_scene)
+		{
+			if (const char* knob = std::getenv("RT_HIP_TILE_LOG2"))
+				q.pixels_log2 = pixels_log2 = static_cast<uint32_t>(std::atoi(knob));
+			q.tile_w_log2 = (pixels_log2 + 1u) / 2u;
+			if (const char* knob = std::getenv("RT_HIP_TILE_W_LOG2"))
+				q.tile_w_log2 = std::min<uint32_t>(static_cast<uint32_t>(std::atoi(knob)), pixels_log2);
+		}
+#endif
 		const uint32_t tile_w = 1u << q.tile_w_log2, tile_h = (1u << pixels_log2) >> q.tile_w_log2;
 		q.tiles_x = (width + tile_w - 1u) / tile_w;
 		q.tiles_y = (local_rows + tile_h - 1u) / tile_h;
@@ -1506,7 +1537,7 @@ namespace rt_hip
 		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene);
+		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u);
 		const uint32_t items = queue.chunks << queue.pixels_log2;
 		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
 		// the device keeps resident, and no more lanes than items

@@ -106,7 +106,10 @@ namespace rt_hip
 		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
 		uint32_t block_items;	   // big scenes: items a wave draws from the launch-wide sequence at a time
 	};
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene);
+	// `host_frame`: the packed pixels go to page-locked HOST memory (every row fragment of a tile is a PCIe write)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame);
+	// internal launch flag, or-ed into the render flags by the callers of launch_render / launch_render_fast: see choose_queue
+	constexpr uint32_t launch_flag_host_frame = 1u << 31;
 
 	// What the big-scene kernels exchange chunk sums through (owned by the context, grown on demand):
 	//   item_sums   16 bytes per item of this rank's rows (a chunk sum on its way to the lane that folds the pixel);

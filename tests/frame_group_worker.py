@@ -22,6 +22,21 @@ import rt_amd  # noqa: E402
 from rt_amd import capi  # noqa: E402
 
 
+def page_nodes(buf):
+    """NUMA node of every whole page of `buf` (move_pages(2) as a query; negative = -errno, e.g. -2 not present)"""
+    import ctypes
+
+    libc = ctypes.CDLL(None, use_errno=True)
+    page = os.sysconf("SC_PAGESIZE")
+    first = (buf.ctypes.data + page - 1) // page * page
+    count = (buf.ctypes.data + buf.nbytes - first) // page
+    pages = (ctypes.c_void_p * count)(*[first + i * page for i in range(count)])
+    status = (ctypes.c_int * count)()
+    if libc.syscall(279, 0, ctypes.c_ulong(count), pages, None, status, 0) != 0:  # SYS_move_pages (x86-64)
+        return None
+    return list(status)
+
+
 def main():
     rank, world = int(sys.argv[1]), int(sys.argv[2])
     group_name, frame_file = sys.argv[3], sys.argv[4]
@@ -30,6 +45,8 @@ def main():
     result = {"rank": rank, "frames_done": 0, "error": None, "ms": [], "stats": None, "info": None, "member_stats": None}
     scene = rt_amd.Scene.named(scene_name) if not scene_name.endswith(".toml") else rt_amd.Scene.load(scene_name)
     pod = scene.set_sampling(spp).describe(width, height)
+    if mode == "numa":
+        os.environ["RT_HIP_NUMA_NODE"] = str(rank % 2)
     tracer = rt_amd.HipRayTracer(0)
     try:
         tracer.join_frame_group(rank, world, group_name, timeout_ms=60000)
@@ -56,6 +73,9 @@ def main():
             result["stats"] = stats
             if rank == 0:
                 np.save(out_dir / f"frame_{f}.npy", np.asarray(frame))
+        if mode == "numa" and rank == 0:
+            result["page_nodes"] = page_nodes(frame)
+            result["host_nodes"] = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
         if result["frames_done"] == frames:
             result["member_stats"] = [tracer.member_stats(r) for r in range(world)]
             result["phases"] = tracer.phases()

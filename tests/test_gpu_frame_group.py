@@ -97,6 +97,25 @@ def test_a_group_of_one_and_a_buffer_mapped_anew(tmp_path):
     assert all(np.array_equal(np.load(out / f"frame_{f}.npy"), want[f]) for f in want)
 
 
+def test_every_stripe_lives_on_the_numa_node_of_the_gpu_that_stores_it(tmp_path):
+    """Two ranks that claim GPUs on different sockets (RT_HIP_NUMA_NODE = rank % 2): before anybody page-locks the
+    shared frame, rank 0 moves each stripe's pages to its owner's node (one move_pages call).  At 1920 pixels a stripe of 8
+    rows is exactly 15 pages."""
+    width, height, spp = 1920, 1080, 2
+    results, out = run_group(tmp_path, 2, width, height, spp, frames=2, mode="numa")
+    assert all(r["error"] is None and r["frames_done"] == 2 for r in results), results
+    pod = rt_amd.Scene.named("basic").set_sampling(spp).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=2, want_rgb=False)
+    assert np.array_equal(np.load(out / "frame_2.npy"), want)
+    nodes, host_nodes = results[0]["page_nodes"], results[0]["host_nodes"]
+    assert nodes is not None and len(nodes) == 2025
+    if len(host_nodes) < 2:
+        pytest.skip(f"this host has NUMA nodes {host_nodes}: nothing to spread over")
+    expected = [(page // 15) % 2 for page in range(2025)]
+    wrong = sum(1 for have, want_node in zip(nodes, expected) if have != want_node)
+    assert wrong <= 20, f"{wrong} of 2025 pages are not on their stripe's node; first stripes: {nodes[:45]}"
+
+
 def test_a_rank_whose_buffer_is_not_the_shared_one_fails_the_frame_everywhere(tmp_path):
     results, _ = run_group(tmp_path, 3, 64, 40, 1, mode="private")
     for r in results:
