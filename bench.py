@@ -469,7 +469,10 @@ def main() -> None:
                 shared = None
                 try:
                     if rank == 0:  # the "caller's back buffer": a shared mapping every rank process maps
-                        np.zeros((args.height, args.width), dtype=np.uint32).tofile(frame_path)
+                        with open(frame_path, "wb") as f:
+                            f.truncate(args.height * args.width * 4)
+                        shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+                        shared[:] = 0  # rt clears its back buffer before every render (src/main.cpp:318): the pages exist, first touched by rank 0
                     dist.barrier()
                     group_tracer, reason = distributed.negotiate_rank_renderer(
                         create=lambda: rt_amd.HipRayTracer(device=device),
@@ -482,7 +485,8 @@ def main() -> None:
                         paths["shared_frame"] = {"status": f"not available: {reason}"}
                         return
                     tracers.append(group_tracer)
-                    shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+                    if shared is None:
+                        shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
                     measure_drop_in("shared_frame", group_tracer, shared,
                                     "inside librt_hip.so: rt_hip_create + rt_hip_join_frame_group; every rank's kernel stores its stripes straight into ONE shared, page-locked back buffer over its own PCIe link; no data-path collective (two shared-memory counters per frame); torch.distributed only hands out the name, votes and keeps time",
                                     "no communicator: rt_hip_join_frame_group's control block in POSIX shared memory (this transport does not use RCCL)")
