@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -221,6 +222,16 @@ namespace
 		return node;
 	}
 
+	// RT_HIP_DEBUG_FRAME=1: one line on stderr per page-lock event (diagnostics for integrators; off by default)
+	bool debug_frame()
+	{
+		static const bool on = [] {
+			const char* knob = std::getenv("RT_HIP_DEBUG_FRAME");
+			return knob && knob[0] == '1';
+		}();
+		return on;
+	}
+
 	// Ask the kernel to move the pages of [ptr, ptr + bytes) to NUMA node `node` (mbind with MPOL_MF_MOVE; the raw
 	// system call, so that nothing links libnuma).  The kernels render straight into the caller's back buffer: on a
 	// two-socket host a buffer on the far socket makes every pixel store cross the socket interconnect — measured on an
@@ -259,8 +270,9 @@ namespace
 	// GPU hosts half of the GPUs hang off each socket; with the whole frame on one node the other half store across
 	// the socket interconnect (+23..37 % kernel time for a GPU that stores a whole frame into far memory,
 	// profiles/r03/shared_frame_numa.txt).  One move_pages(2) call with a target node per page: no memory policy is
-	// installed and no mapping is split.  Pages have to be present to be moved, so they are touched first (a read per
-	// page: the content stays); pages that are page-locked or mapped by another process stay where they are.  Best effort.
+	// installed and no mapping is split.  Pages have to be present to be moved, so they are touched first (the content
+	// stays; nobody else writes the frame at this point: the caller is inside rt_hip_render and no launch has been
+	// made); pages that are page-locked or mapped by another process stay where they are.  Best effort.
 	void place_stripes(void* ptr, size_t bytes, uint32_t width, uint32_t height, uint32_t stripe_rows, const std::vector<int>& node_of_rank)
 	{
 #ifdef SYS_move_pages
@@ -289,7 +301,6 @@ namespace
 		pages.reserve(count);
 		nodes.reserve(count);
 		const size_t row_bytes = static_cast<size_t>(width) * sizeof(uint32_t);
-		volatile unsigned char sink = 0;
 		for (size_t i = 0; i < count; i++)
 		{
 			const uintptr_t address = begin + i * static_cast<size_t>(page);
@@ -297,7 +308,11 @@ namespace
 			const int node = node_of_rank[(row / stripe_rows) % node_of_rank.size()];
 			if (node < 0 || node >= 1024)
 				continue;
-			sink = static_cast<unsigned char>(sink + *reinterpret_cast<const volatile unsigned char*>(address)); // present from here on
+			// present — and this process's own — from here on: the page's first byte is written back as it was read.  A read
+			// alone settles for the kernel's shared zero page on memory that was allocated and never written, and an atomic
+			// OR of nothing is turned into a fence by the compiler (no access at all).
+			volatile unsigned char* const first_byte = reinterpret_cast<volatile unsigned char*>(address);
+			*first_byte = *first_byte;
 			pages.push_back(reinterpret_cast<void*>(address));
 			nodes.push_back(node);
 		}
@@ -305,20 +320,17 @@ namespace
 			return;
 		std::vector<int> status(pages.size(), 0);
 		constexpr int mpol_mf_move = 2;
-		(void)syscall(SYS_move_pages, 0, static_cast<unsigned long>(pages.size()), pages.data(), nodes.data(), status.data(), mpol_mf_move);
+		const long rc = syscall(SYS_move_pages, 0, static_cast<unsigned long>(pages.size()), pages.data(), nodes.data(), status.data(), mpol_mf_move);
+		if (debug_frame())
+		{
+			size_t arrived = 0, busy = 0, other = 0;
+			for (size_t i = 0; i < pages.size(); i++)
+				(status[i] == nodes[i] ? arrived : status[i] == -EBUSY ? busy : other)++;
+			std::fprintf(stderr, "rt_hip: placed the stripes of back buffer %p: move_pages returned %ld (errno %d); %zu of %zu pages on their node, %zu busy, %zu other (first status %d)\n", ptr, rc, rc ? errno : 0, arrived, pages.size(), busy, other, status[0]);
+		}
 #else
 		(void)ptr, (void)bytes, (void)width, (void)height, (void)stripe_rows, (void)node_of_rank;
 #endif
-	}
-
-	// RT_HIP_DEBUG_FRAME=1: one line on stderr per page-lock event (diagnostics for integrators; off by default)
-	bool debug_frame()
-	{
-		static const bool on = [] {
-			const char* knob = std::getenv("RT_HIP_DEBUG_FRAME");
-			return knob && knob[0] == '1';
-		}();
-		return on;
 	}
 
 	// Drop the page-lock.  hipHostUnregister fails when the caller has already unmapped the buffer (the driver dropped

@@ -341,3 +341,28 @@ def test_join_ranks_gives_up_after_its_deadline():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert "status 6" in out.stdout and "FRAME_OK" in out.stdout, out.stdout + out.stderr
     assert "'transport': 'none'" in out.stdout
+
+
+def test_the_back_buffer_ends_up_on_the_numa_node_of_the_gpu_that_stores_into_it(monkeypatch):
+    """Memory that was allocated and never written (calloc: every page is still the kernel's zero page), the case of a
+    back buffer the caller has not cleared yet: after the first render every page is a real page on the node the context
+    was told its GPU hangs off — through the single-GPU call (mbind) and through a direct frame of two members
+    (move_pages, stripe by stripe), for each node of the host in turn."""
+    import os
+
+    from tests.frame_group_worker import page_nodes
+
+    nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+    width, height = 1920, 136
+    pod = rt_amd.Scene.named("basic").set_sampling(1).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=1, want_rgb=False)
+    for node in nodes:
+        monkeypatch.setenv("RT_HIP_NUMA_NODE", str(node))
+        for make in (lambda: rt_amd.HipRayTracer(0), lambda: rt_amd.HipRayTracer(devices=[0, 0], peer_copy=True, direct_frame=True)):
+            t = make()
+            frame = np.zeros((height, width), dtype=np.uint32)
+            got, _, _ = t.render(pod, width, height, seed=1, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=frame)
+            assert np.array_equal(got, want)
+            placed = page_nodes(frame)
+            assert placed is not None and set(placed) == {node}, (node, sorted(set(placed)))
+            t.close()
