@@ -16,6 +16,7 @@
 #include "../../include/rt_hip.h"
 
 #include <atomic>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
@@ -27,9 +28,36 @@ namespace
 	// RT_HIP_DEVICES picks the GPUs: unset = GPU 0 (or RT_HIP_DEVICE=<n>); "all" = every visible GPU; "0,1,2,3" = those, the
 	// first being the root that assembles the frame.  More than one GPU = one rt_hip_create_multi context: the frame is
 	// split into row stripes, gathered over RCCL and delivered by the same single blocking call.
+	//
+	// RT_HIP_GROUP="<shm name>:<rank>:<world>" makes this process ONE RANK of a renderer whose ranks are processes, one per
+	// GPU (RT_HIP_DEVICE picks this process's): rt_hip_create + rt_hip_join_frame_group.  The back buffer the driver hands
+	// to render() must then be every rank's mapping of one shared buffer (rt_headless --shared-frame); render() returns on
+	// every rank when the whole frame is in it.
 	rt_hip_status create_context(rt_hip_ctx** ctx)
 	{
 		const char* list = std::getenv("RT_HIP_DEVICES");
+		if (const char* group = std::getenv("RT_HIP_GROUP"); group && *group)
+		{
+			char name[208] = {};
+			int rank = -1, world = 0;
+			const char* const first_colon = std::strchr(group, ':');
+			if (!first_colon || static_cast<size_t>(first_colon - group) >= sizeof(name) || std::sscanf(first_colon, ":%d:%d", &rank, &world) != 2)
+			{
+				std::cerr << "error: hip_ray_tracer: RT_HIP_GROUP must look like /name:rank:world\n";
+				return RT_HIP_INVALID_ARGUMENT;
+			}
+			std::memcpy(name, group, static_cast<size_t>(first_colon - group));
+			const char* device = std::getenv("RT_HIP_DEVICE");
+			if (const rt_hip_status st = rt_hip_create(ctx, device ? std::atoi(device) : 0))
+				return st;
+			if (const rt_hip_status st = rt_hip_join_frame_group(*ctx, rank, world, name, 0))
+			{
+				rt_hip_destroy(*ctx); // (keeps the message)
+				*ctx = nullptr;
+				return st;
+			}
+			return RT_HIP_OK;
+		}
 		if (!list || !*list)
 		{
 			const char* device = std::getenv("RT_HIP_DEVICE");
@@ -94,7 +122,8 @@ namespace
 				return;
 			if (!ctx && create_context(&ctx) != RT_HIP_OK)
 			{
-				std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
+				if (rt_hip_last_error()[0])
+					std::cerr << "error: hip_ray_tracer: " << rt_hip_last_error() << "\n";
 				failed_to_create = true;
 				return;
 			}

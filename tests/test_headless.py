@@ -132,3 +132,40 @@ def test_device_list_errors_are_reported_without_a_gpu(tmp_path):
         if "error: hip_ray_tracer:" in out.stderr:
             data = ppm.read_bytes()
             assert set(data[len(b"P6\n16 8\n255\n") :]) == {0}
+
+
+@pytest.mark.gpu
+def test_three_rt_headless_processes_render_one_frame_into_a_shared_back_buffer(tmp_path):
+    """`--shared-frame NAME --rank R --world N`: three driver processes, each with the plug-in as one rank of a frame group
+    (RT_HIP_GROUP -> rt_hip_join_frame_group), all on the box's one GPU; the back buffer is a POSIX shared-memory object all
+    three map.  Rank 0's PPM is the oracle's frame; two frames are rendered (rank 0 clears the buffer in between)."""
+    import os
+    import uuid
+
+    import rt_amd
+    from oracle import binding as oracle
+    from tests.conftest import unpack
+
+    name = f"rt_hip_headless_{uuid.uuid4().hex[:10]}"
+    ppm = tmp_path / "frame.ppm"
+    common = ["--renderer", "hip", "--scene", "basic.toml", "--size", "100x61", "--spp", "4", "--seed", "3", "--frames", "2", "--shared-frame", name, "--world", "3"]
+    procs = [subprocess.Popen([str(BIN), *common, "--rank", str(r), "--out", str(ppm)], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(3)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0 and "error:" not in err, err
+    assert "back buffer is the shared mapping" in outs[1][0]
+    header = b"P6\n100 61\n255\n"
+    got = np.frombuffer(ppm.read_bytes()[len(header) :], dtype=np.uint8).reshape(61, 100, 3)
+    scene = rt_amd.Scene.named("basic").set_sampling(4)
+    want, _, _ = oracle.render(scene.describe(100, 61), 100, 61, seed=3, want_rgb=False)
+    assert np.array_equal(got, unpack(want)[..., :3])
+    assert not [f for f in os.listdir("/dev/shm") if name in f]
+
+
+def test_a_malformed_group_is_reported_in_the_reference_error_style(tmp_path):
+    import os
+
+    out = run("--renderer", "hip", "--scene", "basic.toml", "--size", "16x8", "--out", str(tmp_path / "x.ppm"), env=dict(os.environ, RT_HIP_GROUP="nonsense"))
+    assert out.returncode == 0 and "error: hip_ray_tracer: RT_HIP_GROUP must look like /name:rank:world" in out.stderr
+    out = run("--renderer", "null", "--scene", "basic.toml", "--size", "16x8", "--shared-frame", "a/b", "--rank", "0", "--world", "1")
+    assert out.returncode == 2 and "--shared-frame NAME needs" in out.stderr

@@ -12,7 +12,8 @@ import csv, glob, json, sys, collections, pathlib
 tag = sys.argv[1]
 note = sys.argv[2] if len(sys.argv) > 2 else ""
 root = pathlib.Path(__file__).resolve().parent.parent
-src = root / "gpurun_out" / "prof"
+import os
+src = root / "gpurun_out" / os.environ.get("PROF_DIR", "prof")  # PROF_DIR=prof_c2: the passes of tools/gpu_traffic_configs.sh
 out = root / "profiles" / tag
 out.mkdir(parents=True, exist_ok=True)
 
