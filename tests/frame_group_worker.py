@@ -53,6 +53,7 @@ def main():
         result["info"] = tracer.comm_info()
         shared = np.memmap(frame_file, dtype=np.uint32, mode="r+", shape=(height, width))
         frame = np.zeros((height, width), dtype=np.uint32) if (mode == "private" and rank == 1) else shared
+        first_of_seed = {}
         for f in range(1, frames + 1):
             if f == 2 and mode == "remap":
                 del frame, shared
@@ -66,17 +67,27 @@ def main():
                 tracer.close()
                 break
             seed = f + (1 if (mode == "mismatch" and rank == 1 and f == 2) else 0)
+            if mode == "many":
+                seed = (f - 1) % 3 + 1
+            flags = {"preview": capi.RT_HIP_FLAG_PREVIEW, "sm": capi.RT_HIP_FLAG_SM_MATERIALS}.get(mode, 0)
             t0 = time.perf_counter()
-            _, rgb, stats = tracer.render(pod, width, height, seed=seed, out=frame, want_rgb=(mode == "float" and rank == 0))
+            _, rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, out=frame, want_rgb=(mode == "float" and rank == 0), stats=(mode != "many" or f <= 3))
             result["ms"].append((time.perf_counter() - t0) * 1e3)
             result["frames_done"] = f
-            result["stats"] = stats
-            if rank == 0:
+            if stats:
+                result["stats"] = stats
+            if rank == 0 and mode == "many" and f > 3:
+                if not np.array_equal(frame, first_of_seed[seed]):
+                    result["error"] = f"frame {f} (seed {seed}) differs from the first frame of that seed in {int((np.asarray(frame) != first_of_seed[seed]).sum())} pixels"
+                    break
+            elif rank == 0:
                 np.save(out_dir / f"frame_{f}.npy", np.asarray(frame))
+                first_of_seed[seed] = np.array(frame)
         if mode == "numa" and rank == 0:
             result["page_nodes"] = page_nodes(frame)
             result["host_nodes"] = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
-        if result["frames_done"] == frames:
+        result["ms"] = result["ms"][-20:]
+        if result["frames_done"] == frames and mode != "many":
             result["member_stats"] = [tracer.member_stats(r) for r in range(world)]
             result["phases"] = tracer.phases()
             result["devices"] = [tracer.member_device(r) for r in range(world)]

@@ -97,6 +97,31 @@ def test_a_group_of_one_and_a_buffer_mapped_anew(tmp_path):
     assert all(np.array_equal(np.load(out / f"frame_{f}.npy"), want[f]) for f in want)
 
 
+def test_the_preview_and_the_sm_material_table_go_through_a_frame_group_too(tmp_path, tracer):
+    from rt_amd import capi
+
+    width, height, spp = 200, 120, 3
+    pod = rt_amd.Scene.named("dielectric").set_sampling(spp).describe(width, height)
+    for mode, flags in (("preview", capi.RT_HIP_FLAG_PREVIEW), ("sm", capi.RT_HIP_FLAG_SM_MATERIALS)):
+        out = tmp_path / mode
+        out.mkdir()
+        results, _ = run_group(out, 3, width, height, spp, scene="dielectric", frames=2, mode=mode)
+        assert all(r["error"] is None and r["frames_done"] == 2 for r in results), results
+        want, _, _ = tracer.render(pod, width, height, seed=2, flags=flags)  # (the single-GPU frames are oracle-checked in test_gpu_parity.py)
+        assert np.array_equal(np.load(out / "frame_2.npy"), want), mode
+
+
+def test_four_hundred_frames_in_a_row_are_each_complete_when_rank_0_returns(tmp_path):
+    """Seeds 1, 2, 3 in turn, 400 tiny frames, four rank processes: a frame that rank 0 saw before every rank's stripes were
+    in — or that a rank started storing into too early — would differ from the first frame of its seed."""
+    results, out = run_group(tmp_path, 4, 160, 100, 1, frames=400, mode="many")
+    assert all(r["error"] is None and r["frames_done"] == 400 for r in results), results
+    pod = rt_amd.Scene.named("basic").set_sampling(1).describe(160, 100)
+    for seed in (1, 2, 3):
+        want, _, _ = oracle.render(pod, 160, 100, seed=seed, want_rgb=False)
+        assert np.array_equal(np.load(out / f"frame_{seed}.npy"), want)
+
+
 def test_every_stripe_lives_on_the_numa_node_of_the_gpu_that_stores_it(tmp_path):
     """Two ranks that claim GPUs on different sockets (RT_HIP_NUMA_NODE = rank % 2): before anybody page-locks the
     shared frame, rank 0 moves each stripe's pages to its owner's node (one move_pages call).  At 1920 pixels a stripe of 8
