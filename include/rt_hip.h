@@ -196,7 +196,12 @@ enum
 	 * is the plug-in's call (shim/hip_ray_tracer.cpp): nothing but the launch and the wait is enqueued — no timing events, no
 	 * zeroing and read-back of the counters — which is what the launch-bound low-resolution preview frames of
 	 * reference src/main.cpp:315-321 want; rt_hip_stats_fetch after such a frame reports render_ms = 0 and segments = 0. */
-	RT_HIP_FLAG_STATS = 1u << 7
+	RT_HIP_FLAG_STATS = 1u << 7,
+	/* Work items of the small-scene kernels are whole 16-sample chunks, or — for launches that hold only a few chunks per
+	 * lane of the device — half chunks: the launch code decides by the size of the launch, and the frame is
+	 * the same bit for bit either way.  These two take the decision away from it (tests; never both). */
+	RT_HIP_FLAG_FORCE_HALF_CHUNKS = 1u << 8,
+	RT_HIP_FLAG_FORCE_WHOLE_CHUNKS = 1u << 9
 };
 
 typedef struct rt_hip_ctx rt_hip_ctx;

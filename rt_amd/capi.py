@@ -26,6 +26,8 @@ RT_HIP_FLAG_PREVIEW = 1 << 4
 RT_HIP_FLAG_FORCE_STREAMED = 1 << 5
 RT_HIP_FLAG_FAST = 1 << 6
 RT_HIP_FLAG_STATS = 1 << 7
+RT_HIP_FLAG_FORCE_HALF_CHUNKS = 1 << 8
+RT_HIP_FLAG_FORCE_WHOLE_CHUNKS = 1 << 9
 RT_HIP_MULTI_PEER_COPY = 1 << 0
 RT_HIP_MULTI_DIRECT_FRAME = 1 << 1
 RT_HIP_TRANSPORT_NONE, RT_HIP_TRANSPORT_RCCL_GATHER, RT_HIP_TRANSPORT_PEER_COPY, RT_HIP_TRANSPORT_DIRECT_FRAME = 0, 1, 2, 3

@@ -1218,8 +1218,10 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: empty frame %ux%u", width, height);
 	if (static_cast<uint64_t>(width) * height > 0xFFFFFFFFull)
 		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: %ux%u exceeds the 32-bit pixel index of image_view", width, height);
-	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST | RT_HIP_FLAG_STATS))
+	if (flags & ~static_cast<uint32_t>(RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_PERSISTENT_FRAME | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST | RT_HIP_FLAG_STATS | RT_HIP_FLAG_FORCE_HALF_CHUNKS | RT_HIP_FLAG_FORCE_WHOLE_CHUNKS))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: unknown flag bits 0x%x", flags);
+	if ((flags & RT_HIP_FLAG_FORCE_HALF_CHUNKS) && (flags & RT_HIP_FLAG_FORCE_WHOLE_CHUNKS))
+		return fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_render_device: RT_HIP_FLAG_FORCE_HALF_CHUNKS and RT_HIP_FLAG_FORCE_WHOLE_CHUNKS exclude each other");
 	if ((flags & RT_HIP_FLAG_FAST) && (flags & (RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW)))
 		return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: RT_HIP_FLAG_FAST applies to mg_ray_tracer's path only (not with RT_HIP_FLAG_SM_MATERIALS / RT_HIP_FLAG_PREVIEW)");
 	if (!ctx->have_scene)
@@ -1296,9 +1298,9 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
-		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame);
+		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags));
 		// small scenes: a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
-		const uint64_t slot_bytes = big_scene ? 0u : 4ull * (static_cast<uint64_t>(queue.chunks) << queue.pixels_log2) * 12u;
+		const uint64_t slot_bytes = big_scene ? 0u : 4ull * tile_slot_bytes(queue);
 		if (slot_bytes > 48u * 1024u)
 			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %u samples per pixel are more than the kernels hold chunk sums for (4096; the reference clamps to 1000, src/scene.cpp:544)", f.samples_per_pixel);
 		// big scenes: they meet in HBM, 16 bytes per chunk of this rank's rows
@@ -1482,7 +1484,7 @@ extern "C" rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_s
 namespace
 {
 	// (RT_HIP_FLAG_PERSISTENT_FRAME and RT_HIP_FLAG_STATS are rt_hip_render's own: they do not travel to the launch)
-	constexpr uint32_t render_flag_mask = RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST;
+	constexpr uint32_t render_flag_mask = RT_HIP_FLAG_FORCE_TILED | RT_HIP_FLAG_FORCE_RESIDENT | RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_PREVIEW | RT_HIP_FLAG_FORCE_STREAMED | RT_HIP_FLAG_FAST | RT_HIP_FLAG_FORCE_HALF_CHUNKS | RT_HIP_FLAG_FORCE_WHOLE_CHUNKS;
 
 	// image_view memory is ordinary pageable host memory (reference src/image.cpp:9-13).  With
 	// RT_HIP_FLAG_PERSISTENT_FRAME it is page-locked on first sight and stays so while the same buffer keeps arriving;

@@ -443,6 +443,13 @@ namespace rt_hip
 		// was spent waiting for the slowest waves.  With items the stragglers' excess is one item, not four tiles' worth.
 		// (For small scenes the per-trip cost is the shading code, and lanes that never start together lose the phase
 		// coherence that keeps it short — profiles/r01/queue_shape_sweep.txt.  They keep one tile per wave.)
+		// half-chunks: how many samples of chunk `chunk` lie in its second half (indices chunk * 16 + 8 ..)
+		__device__ __forceinline__ uint32_t parked_samples(uint32_t samples_per_pixel, uint32_t chunk)
+		{
+			const uint32_t first = chunk * sample_chunk + sample_chunk / 2u;
+			return samples_per_pixel > first ? min(samples_per_pixel - first, sample_chunk / 2u) : 0u;
+		}
+
 		__device__ __forceinline__ unsigned long long fetch_items(device_counters* counters, uint32_t count) // call converged
 		{
 			unsigned long long base = 0;
@@ -468,7 +475,13 @@ namespace rt_hip
 			return { __uint_as_float(static_cast<uint32_t>(xy)), __uint_as_float(static_cast<uint32_t>(xy >> 32)), __uint_as_float(z) };
 		}
 
-		template <int NS, bool SM>
+		// HALF (small and resident kernels, short launches; see choose_queue): the unit of work is HALF a chunk, 8 samples.
+		// The chunk sum stays what the contract says — sixteen samples added in sample order — so the lane that traces a
+		// chunk's second half cannot add anything up itself: it parks its (up to) eight sample values in the tile's LDS
+		// slot, next to the first half's partial sum, and the fold at the end of the wave continues that partial sum with
+		// them, in order.  Twice as many, half as long items: what a launch with two or three chunks per lane needs to end
+		// evenly (profiles/r03/chunk_probe.txt).
+		template <int NS, bool SM, bool HALF = false>
 		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
@@ -512,9 +525,13 @@ namespace rt_hip
 			constexpr bool ROLLING = NS < 0;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
-			const uint32_t items = q.chunks << q.pixels_log2; // of one pixel tile: P x K
-			// chunk-sum slots of this wave's tile (one tile per wave; the rolling kernels keep no sums in LDS)
-			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * items * 3u;
+			static_assert(!HALF || NS >= 0, "half-chunks exist in the small and the resident kernel only");
+			const uint32_t chunk_items = q.chunks << q.pixels_log2;	   // chunks of one pixel tile: P x K
+			const uint32_t items = HALF ? 2u * chunk_items : chunk_items; // work items of the tile
+			// chunk-sum slots of this wave's tile (one tile per wave; the rolling kernels keep no sums in LDS): 3 floats per
+			// chunk; HALF: 27 — the first half's partial sum, then the second half's eight sample values
+			constexpr uint32_t slot_floats = HALF ? half_chunk_slot_floats : 3u;
+			float* const slots = reinterpret_cast<float*>(lds + table_float4s) + static_cast<size_t>(wave) * chunk_items * slot_floats;
 			const uint32_t tile_w = 1u << q.tile_w_log2;
 			const uint32_t tile_h = (1u << q.pixels_log2) >> q.tile_w_log2;
 
@@ -567,9 +584,24 @@ namespace rt_hip
 					float sum = 0.0f;
 					if (live)
 					{
-						sum = sums[pixel * 3u + channel];
-						for (uint32_t c = 1; c < q.chunks; c++)
-							sum = sum + sums[((c << q.pixels_log2) + pixel) * 3u + channel];
+						if (HALF)
+						{
+							for (uint32_t c = 0; c < q.chunks; c++)
+							{
+								const float* const slot_of_chunk = sums + ((c << q.pixels_log2) + pixel) * slot_floats;
+								float chunk_sum = slot_of_chunk[channel]; // samples 0..7 of the chunk, then 8.. in order
+								const uint32_t parked = parked_samples(p.samples_per_pixel, c);
+								for (uint32_t j = 0; j < parked; j++)
+									chunk_sum = chunk_sum + slot_of_chunk[3u + j * 3u + channel];
+								sum = c ? sum + chunk_sum : chunk_sum;
+							}
+						}
+						else
+						{
+							sum = sums[pixel * 3u + channel];
+							for (uint32_t c = 1; c < q.chunks; c++)
+								sum = sum + sums[((c << q.pixels_log2) + pixel) * 3u + channel];
+						}
 					}
 					const float mean = sum / static_cast<float>(p.samples_per_pixel);
 					const size_t o = static_cast<size_t>(output_row(live ? ly : 0u, p)) * p.width + lx;
@@ -588,11 +620,27 @@ namespace rt_hip
 					const uint32_t ly = y0 + (pixel >> q.tile_w_log2);
 					if (lx < p.width && ly < p.local_rows)
 					{
-						vec3 colour = { sums[pixel * 3u], sums[pixel * 3u + 1u], sums[pixel * 3u + 2u] };
-						for (uint32_t c = 1; c < q.chunks; c++)
+						vec3 colour = { 0.0f, 0.0f, 0.0f };
+						if (HALF)
 						{
-							const uint32_t at = ((c << q.pixels_log2) + pixel) * 3u;
-							colour = colour + vec3{ sums[at], sums[at + 1u], sums[at + 2u] };
+							for (uint32_t c = 0; c < q.chunks; c++)
+							{
+								const float* const slot_of_chunk = sums + ((c << q.pixels_log2) + pixel) * slot_floats;
+								vec3 chunk_sum = { slot_of_chunk[0], slot_of_chunk[1], slot_of_chunk[2] };
+								const uint32_t parked = parked_samples(p.samples_per_pixel, c);
+								for (uint32_t j = 0; j < parked; j++)
+									chunk_sum = chunk_sum + vec3{ slot_of_chunk[3u + j * 3u], slot_of_chunk[4u + j * 3u], slot_of_chunk[5u + j * 3u] };
+								colour = c ? colour + chunk_sum : chunk_sum;
+							}
+						}
+						else
+						{
+							colour = { sums[pixel * 3u], sums[pixel * 3u + 1u], sums[pixel * 3u + 2u] };
+							for (uint32_t c = 1; c < q.chunks; c++)
+							{
+								const uint32_t at = ((c << q.pixels_log2) + pixel) * 3u;
+								colour = colour + vec3{ sums[at], sums[at + 1u], sums[at + 2u] };
+							}
 						}
 						finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
 					}
@@ -629,6 +677,34 @@ namespace rt_hip
 			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
 			const auto end_sample = [&](vec3 contribution)
 			{
+				if (HALF)
+				{
+					// slot = (half-chunk index << pixels_log2) + pixel; its chunk's LDS slot; sample bit 3 = second half
+					const uint32_t half_chunk = slot >> q.pixels_log2;
+					float* const slot_of_chunk = slots + ((((half_chunk >> 1u) << q.pixels_log2) + (slot & ((1u << q.pixels_log2) - 1u))) * slot_floats);
+					if (st.sample & 8u) // second half: the sample's value is parked as it is
+					{
+						float* const place = slot_of_chunk + 3u + (st.sample & 7u) * 3u;
+						place[0] = contribution.x;
+						place[1] = contribution.y;
+						place[2] = contribution.z;
+					}
+					else
+						st.chunk_sum = st.chunk_sum + contribution;
+					if (++st.sample < st.sample_end)
+						mode = lane_restart;
+					else
+					{
+						if (!((st.sample - 1u) & 8u)) // first half: its partial sum
+						{
+							slot_of_chunk[0] = st.chunk_sum.x;
+							slot_of_chunk[1] = st.chunk_sum.y;
+							slot_of_chunk[2] = st.chunk_sum.z;
+						}
+						mode = lane_free;
+					}
+					return;
+				}
 				st.chunk_sum = st.chunk_sum + contribution;
 				if (++st.sample < st.sample_end)
 					mode = lane_restart;
@@ -820,16 +896,20 @@ namespace rt_hip
 				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
 				// a free lane starts on chunk `chunk` of the pixel at (lx, ly) of this rank's rows
+				// (HALF: `chunk` counts half-chunks of 8 samples; one that lies wholly behind the last sample is empty)
 				const auto start_item = [&](uint32_t lx, uint32_t ly, uint32_t chunk)
 				{
+					constexpr uint32_t item_samples = HALF ? sample_chunk / 2u : sample_chunk;
+					if (HALF && chunk * item_samples >= p.samples_per_pixel)
+						return; // (the lane stays free and asks again)
 					const uint32_t gy = global_row(ly, p);
 					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
 					st.fx = static_cast<float>(lx);
 					st.fy = static_cast<float>(gy);
 					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
-					st.sample = chunk * sample_chunk;
-					st.sample_end = min(st.sample + sample_chunk, p.samples_per_pixel);
+					st.sample = chunk * item_samples;
+					st.sample_end = min(st.sample + item_samples, p.samples_per_pixel);
 					mode = lane_restart;
 				};
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
@@ -1395,6 +1475,14 @@ namespace rt_hip
 				}
 				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(known.per_cu)));
 			}
+			if constexpr (NS >= 0 && !SM) // (the sm table keeps whole chunks: one set of kernels fewer to build)
+			{
+				if (queue.halves)
+				{
+					hipLaunchKernelGGL((render_queue<NS, SM, true>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
+					return;
+				}
+			}
 			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 		}
 
@@ -1443,7 +1531,7 @@ namespace rt_hip
 		return samples_per_pixel >= 32u ? RT_HIP_KERNEL_STREAMED : RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks)
 	{
 		queue_params q{};
 		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk; // K chunks per pixel
@@ -1470,9 +1558,26 @@ namespace rt_hip
 			if (pixels_log2 > 2 && (pixels >> pixels_log2) < 49152u)
 				pixels_log2--;
 		}
+		// Half-chunks (render_queue<.., HALF>): a launch that has only a few chunks per lane of the device ends unevenly —
+		// a rank's 1/8 share of a 64-spp frame holds two per lane and took 0.21 ms for 0.09 ms of work; with 8-sample items
+		// 0.13-0.14 (profiles/r03/chunk_probe.txt: 1/4 share -11 %, nothing from eight chunks per lane upwards, where the
+		// parking would only cost).  64 half-chunks per wave, one per lane; tiles of at least four pixels.
+		if (half_chunks && !big_scene && samples_per_pixel > sample_chunk / 2u && q.chunks <= 16u)
+		{
+			constexpr uint64_t resident_lanes = 256ull * 4ull * 8ull * 64ull; // an MI355X at 8 waves per SIMD
+			if (half_chunks == 2 || static_cast<uint64_t>(width) * local_rows * q.chunks < 6ull * resident_lanes)
+			{
+				q.halves = 1u;
+				pixels_log2 = 2u;
+				while (pixels_log2 < 7u && ((2u * q.chunks) << (pixels_log2 + 1u)) <= 64u)
+					pixels_log2++;
+			}
+		}
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
-		if (host_frame && !big_scene)
+		if (host_frame && !big_scene && q.halves)
+			q.tile_w_log2 = std::min(pixels_log2, 4u); // (rows as wide as the tile allows: see below)
+		else if (host_frame && !big_scene)
 		{
 			// The finished pixels of a tile leave the wave as one store per tile, a row fragment of tile_w pixels per tile
 			// row; into page-locked host memory every fragment is a PCIe write.  Fragments of 8 and 16 bytes (2 x 2, 4 x 4,
@@ -1537,14 +1642,14 @@ namespace rt_hip
 		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u);
-		const uint32_t items = queue.chunks << queue.pixels_log2;
+		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags));
+
 		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
 		// the device keeps resident, and no more lanes than items
 		const uint64_t total_items = static_cast<uint64_t>(frame.width) * frame.local_rows * queue.chunks;
 		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_items + block_threads - 1u) / block_threads))) // capped to the resident count at launch
 									: dim3((queue.tiles_x + 3u) / 4u, queue.tiles_y);
-		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * items * 3u * sizeof(float);
+		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * tile_slot_bytes(queue);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;

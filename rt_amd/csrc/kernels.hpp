@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../../include/rt_hip.h" // (the render flags: half_chunk_choice)
 
 namespace rt_hip
 {
@@ -91,7 +92,11 @@ namespace rt_hip
 	};
 
 	// pixel sums are taken in chunks of this many consecutive samples (arithmetic contract; see oracle/cpu_ref.cpp)
+#ifdef RT_HIP_SAMPLE_CHUNK // (timing experiments only: frames of such a build are not the contract's)
+	constexpr uint32_t sample_chunk = RT_HIP_SAMPLE_CHUNK;
+#else
 	constexpr uint32_t sample_chunk = 16;
+#endif
 
 	// Work distribution.  The unit of work is one ITEM = one chunk of 16 consecutive samples of one pixel (K = chunks per
 	// pixel).  Small scenes: the frame is cut into pixel tiles of P = 2^pixels_log2 pixels, one tile (P x K items) per wave,
@@ -105,9 +110,24 @@ namespace rt_hip
 		uint32_t tile_w_log2;	   // a tile is 2^tile_w_log2 columns wide
 		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
 		uint32_t block_items;	   // big scenes: items a wave draws from the launch-wide sequence at a time
+		uint32_t halves;		   // small scenes, short launches: 1 = the work items are HALF chunks (8 samples), see render_queue
 	};
+	// LDS floats per chunk of a tile: its sum — or, with half-chunks, the first half's partial sum and the second half's 8 x 3 sample values
+	constexpr uint32_t half_chunk_slot_floats = 3u + 3u * (sample_chunk / 2u);
+	inline size_t tile_slot_bytes(const queue_params& q) // of ONE wave's tile
+	{
+		return static_cast<size_t>(q.chunks << q.pixels_log2) * (q.halves ? half_chunk_slot_floats : 3u) * sizeof(float);
+	}
 	// `host_frame`: the packed pixels go to page-locked HOST memory (every row fragment of a tile is a PCIe write)
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame);
+	// `half_chunks`: 0 = whole chunks (the sm table's kernels have no half-chunk build; RT_HIP_FLAG_FORCE_WHOLE_CHUNKS),
+	// 1 = by the size of the launch, 2 = half chunks wherever the samples allow (RT_HIP_FLAG_FORCE_HALF_CHUNKS)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks);
+	inline int half_chunk_choice(uint32_t flags)
+	{
+		if (flags & (RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_FORCE_WHOLE_CHUNKS))
+			return 0;
+		return (flags & RT_HIP_FLAG_FORCE_HALF_CHUNKS) ? 2 : 1;
+	}
 	// internal launch flag, or-ed into the render flags by the callers of launch_render / launch_render_fast: see choose_queue
 	constexpr uint32_t launch_flag_host_frame = 1u << 31;
 
