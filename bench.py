@@ -468,12 +468,19 @@ def main() -> None:
                 frame_path = f"/dev/shm/{names[0]}_frame"
                 shared = None
                 try:
+                    created = True
                     if rank == 0:  # the "caller's back buffer": a shared mapping every rank process maps
-                        with open(frame_path, "wb") as f:
-                            f.truncate(args.height * args.width * 4)
-                        shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
-                        shared[:] = 0  # rt clears its back buffer before every render (src/main.cpp:318): the pages exist, first touched by rank 0
-                    dist.barrier()
+                        try:
+                            with open(frame_path, "wb") as f:
+                                f.truncate(args.height * args.width * 4)
+                            shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+                            shared[:] = 0  # rt clears its back buffer before every render (src/main.cpp:318): the pages exist, first touched by rank 0
+                        except OSError as e:
+                            log(f"rank 0: the shared frame {frame_path} could not be made: {e}")
+                            created = False
+                    if not distributed.all_agree(created, vote_device):  # (also the barrier: the file exists before anybody maps it)
+                        paths["shared_frame"] = {"status": f"not available: {frame_path} could not be created"}
+                        return
                     group_tracer, reason = distributed.negotiate_rank_renderer(
                         create=lambda: rt_amd.HipRayTracer(device=device),
                         join=lambda t, unique: t.join_frame_group(rank, world, f"/{names[0]}_group", timeout_ms=int(min(deadline, 120.0) * 1e3)),
