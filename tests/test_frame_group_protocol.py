@@ -9,15 +9,25 @@ import pytest
 from tests.conftest import ROOT
 
 
-@pytest.fixture(scope="module")
-def ranks_exe(tmp_path_factory):
+def build(tmp_path_factory, name, extra):
     if shutil.which("g++") is None:
         pytest.skip("needs g++")
-    exe = tmp_path_factory.mktemp("frame_group") / "frame_group_ranks"
-    build = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pthread", str(ROOT / "tests" / "native" / "frame_group_ranks.cpp"), "-o", str(exe), "-lrt"],
-                           capture_output=True, text=True, timeout=300)
-    assert build.returncode == 0, build.stderr[-3000:]
+    exe = tmp_path_factory.mktemp("frame_group") / name
+    done = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Wextra", "-pthread", *extra, str(ROOT / "tests" / "native" / "frame_group_ranks.cpp"), "-o", str(exe), "-lrt"],
+                          capture_output=True, text=True, timeout=300)
+    assert done.returncode == 0, done.stderr[-3000:]
     return exe
+
+
+@pytest.fixture(scope="module")
+def ranks_exe(tmp_path_factory):
+    return build(tmp_path_factory, "frame_group_ranks", [])
+
+
+@pytest.fixture(scope="module")
+def sanitized_exe(tmp_path_factory):
+    """the same program under AddressSanitizer + UndefinedBehaviorSanitizer (host code: sanitizers run on the CPU build only)"""
+    return build(tmp_path_factory, "frame_group_ranks_asan", ["-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all"])
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8])
@@ -31,3 +41,9 @@ def test_a_rank_that_misbehaves_ends_the_frame_on_every_rank(ranks_exe, scenario
     """private buffer / other arguments / a rank that leaves / never joins / goes silent: nobody hangs, everybody is told why."""
     run = subprocess.run([str(ranks_exe), scenario, "4"], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.startswith("OK:"), run.stdout + run.stderr
+
+
+@pytest.mark.parametrize("scenario", ["frames", "private", "leaves", "silent"])
+def test_the_protocol_is_clean_under_address_and_undefined_behaviour_sanitizers(sanitized_exe, scenario):
+    run = subprocess.run([str(sanitized_exe), scenario, "3"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and run.stdout.startswith("OK:") and "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stdout + run.stderr[-3000:]
