@@ -1573,6 +1573,11 @@ namespace rt_hip
 					pixels_log2++;
 			}
 		}
+		// frames of headline size and beyond at 256 spp: 16 pixels (256 items) per wave beat 8 — half as many waves to start
+		// and to fold (HBM: 2.62 against 2.63 ms at 1080p, 10.4 against 10.6 at 4K; profiles/r03/tile_shapes.txt) — while a
+		// half frame still prefers 8 (1.39 against 1.34)
+		if (!big_scene && !q.halves && pixels_log2 == 3u && (q.chunks << 4u) <= 256u && ((static_cast<uint64_t>(width) * local_rows) >> 4u) >= 98304u)
+			pixels_log2 = 4u;
 		q.pixels_log2 = pixels_log2;
 		q.tile_w_log2 = (pixels_log2 + 1u) / 2u; // 16x8, 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
 		if (host_frame && !big_scene && q.halves)
@@ -1589,12 +1594,8 @@ namespace rt_hip
 			// 8 x 1 (half as many store instructions: as fast as the frame left in HBM whichever socket the memory is on).
 			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
 			if (pixels_log2 == 3u && (q.chunks << 4u) <= 256u && (pixels >> 4u) >= 49152u)
-			{
 				q.pixels_log2 = pixels_log2 = 4u;
-				q.tile_w_log2 = 3u;
-			}
-			else
-				q.tile_w_log2 = std::min(pixels_log2, 4u);
+			q.tile_w_log2 = (pixels_log2 == 4u && q.chunks == 16u) ? 3u : std::min(pixels_log2, 4u);
 		}
 #ifdef RT_HIP_QUEUE_KNOBS
 		// experiment builds only (tools/gpu_tile_shapes.py): tile size and width from the environment, per launch
