@@ -1298,14 +1298,14 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
-		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags));
+		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes);
 		// small scenes: a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
 		const uint64_t slot_bytes = big_scene ? 0u : 4ull * tile_slot_bytes(queue);
 		if (slot_bytes > 48u * 1024u)
 			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %u samples per pixel are more than the kernels hold chunk sums for (4096; the reference clamps to 1000, src/scene.cpp:544)", f.samples_per_pixel);
 		// big scenes: they meet in HBM, 16 bytes per chunk of this rank's rows
 		size_t sums_bytes = 0, done_bytes = 0;
-		rolling_buffer_bytes(queue, width, f.local_rows, big_scene, sums_bytes, done_bytes);
+		rolling_buffer_bytes(queue, f.samples_per_pixel, width, f.local_rows, big_scene, sums_bytes, done_bytes);
 		if (sums_bytes > (64ull << 30))
 			return fail(RT_HIP_UNSUPPORTED, "rt_hip_render_device: %ux%u at %u samples per pixel needs %zu GiB for the chunk sums of a scene of this size", width, height, f.samples_per_pixel, sums_bytes >> 30);
 		if (sums_bytes)

@@ -525,7 +525,6 @@ namespace rt_hip
 			constexpr bool ROLLING = NS < 0;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
-			static_assert(!HALF || NS >= 0, "half-chunks exist in the small and the resident kernel only");
 			const uint32_t chunk_items = q.chunks << q.pixels_log2;	   // chunks of one pixel tile: P x K
 			const uint32_t items = HALF ? 2u * chunk_items : chunk_items; // work items of the tile
 			// chunk-sum slots of this wave's tile (one tile per wave; the rolling kernels keep no sums in LDS): 3 floats per
@@ -542,7 +541,9 @@ namespace rt_hip
 			uint32_t next_item = 0; // wave-uniform queue head
 
 			// rolling items: the launch-wide sequence, the block this wave is handing out, the block drawn ahead
-			const unsigned long long total_items = static_cast<unsigned long long>(p.width) * p.local_rows * q.chunks;
+			// rolling + HALF: a pixel is cut into items of q.item_samples consecutive samples, whatever the chunks are
+			const uint32_t items_per_pixel = (ROLLING && HALF) ? (p.samples_per_pixel + q.item_samples - 1u) / q.item_samples : q.chunks;
+			const unsigned long long total_items = static_cast<unsigned long long>(p.width) * p.local_rows * items_per_pixel;
 			unsigned long long block_next = 0, block_end = 0; // [block_next, block_end): not yet given to a lane
 			unsigned long long prefetched = 0;				  // first item of the block after that
 			uint32_t prefetched_count = 64u;				  // (the first block is a whole wave's worth: every lane starts at once)
@@ -653,6 +654,41 @@ namespace rt_hip
 				const uint32_t row = slot / p.width; // hand-out order: bottom row first
 				const uint32_t lx = slot - row * p.width;
 				const uint32_t ly = p.local_rows - 1u - row;
+				if (HALF)
+				{
+					// sub-chunk items: every sample's value went to its own place (end_sample); the lane that brings a pixel's
+					// last item adds them up as the contract says — sixteen in sample order per chunk, chunks in chunk order
+					unsigned long long* const samples = item_sums + 2u * static_cast<size_t>(slot) * p.samples_per_pixel;
+					asm volatile("s_waitcnt vmcnt(0) ; the samples have left before the arrival is counted" ::: "memory");
+					const uint32_t before = __hip_atomic_fetch_add(&pixel_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					if (before + 1u == items_per_pixel)
+					{
+						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+						vec3 colour = { 0.0f, 0.0f, 0.0f };
+						for (uint32_t first = 0; first < p.samples_per_pixel; first += sample_chunk)
+						{
+							const uint32_t end = min(first + sample_chunk, p.samples_per_pixel);
+							vec3 chunk_sum = { 0.0f, 0.0f, 0.0f };
+							uint32_t i = first;
+							for (; i + 8u <= end; i += 8u) // eight loads in flight, then eight additions in sample order
+							{
+								vec3 value[8];
+#pragma unroll
+								for (uint32_t k = 0; k < 8u; k++)
+									value[k] = read_sum(samples + 2u * (i + k));
+#pragma unroll
+								for (uint32_t k = 0; k < 8u; k++)
+									chunk_sum = chunk_sum + value[k];
+							}
+							for (; i < end; i++)
+								chunk_sum = chunk_sum + read_sum(samples + 2u * i);
+							colour = first ? colour + chunk_sum : chunk_sum;
+						}
+						__hip_atomic_store(&pixel_done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // as the next launch expects it
+						finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+					}
+					return;
+				}
 				if (q.chunks == 1u) // (wave-uniform)
 				{
 					finish_pixel(st.chunk_sum, p, lx, ly, out_rgba, out_rgb);
@@ -677,6 +713,18 @@ namespace rt_hip
 			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
 			const auto end_sample = [&](vec3 contribution)
 			{
+				if (HALF && ROLLING)
+				{
+					publish_sum(item_sums + 2u * (static_cast<size_t>(slot) * p.samples_per_pixel + st.sample), contribution);
+					if (++st.sample < st.sample_end)
+						mode = lane_restart;
+					else
+					{
+						complete_item();
+						mode = lane_free;
+					}
+					return;
+				}
 				if (HALF)
 				{
 					// slot = (half-chunk index << pixels_log2) + pixel; its chunk's LDS slot; sample bit 3 = second half
@@ -899,8 +947,8 @@ namespace rt_hip
 				// (HALF: `chunk` counts half-chunks of 8 samples; one that lies wholly behind the last sample is empty)
 				const auto start_item = [&](uint32_t lx, uint32_t ly, uint32_t chunk)
 				{
-					constexpr uint32_t item_samples = HALF ? sample_chunk / 2u : sample_chunk;
-					if (HALF && chunk * item_samples >= p.samples_per_pixel)
+					const uint32_t item_samples = (HALF && ROLLING) ? q.item_samples : (HALF ? sample_chunk / 2u : sample_chunk);
+					if (HALF && !ROLLING && chunk * item_samples >= p.samples_per_pixel)
 						return; // (the lane stays free and asks again)
 					const uint32_t gy = global_row(ly, p);
 					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
@@ -972,13 +1020,13 @@ namespace rt_hip
 							uint32_t pixel, chunk;
 							if ((total_items >> 32) == 0) // (wave-uniform)
 							{
-								pixel = static_cast<uint32_t>(item) / q.chunks;
-								chunk = static_cast<uint32_t>(item) - pixel * q.chunks;
+								pixel = static_cast<uint32_t>(item) / items_per_pixel;
+								chunk = static_cast<uint32_t>(item) - pixel * items_per_pixel;
 							}
 							else
 							{
-								pixel = static_cast<uint32_t>(item / q.chunks);
-								chunk = static_cast<uint32_t>(item - static_cast<unsigned long long>(pixel) * q.chunks);
+								pixel = static_cast<uint32_t>(item / items_per_pixel);
+								chunk = static_cast<uint32_t>(item - static_cast<unsigned long long>(pixel) * items_per_pixel);
 							}
 							const uint32_t row = pixel / p.width; // bottom row first
 							slot = pixel;
@@ -1463,11 +1511,18 @@ namespace rt_hip
 #else
 				constexpr bool fast_arithmetic = false;
 #endif
-				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM, fast_arithmetic)];
+				const bool sub_chunk_items = !SM && queue.halves;
+				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM, fast_arithmetic, sub_chunk_items)];
 				if (known.lds_bytes != lds_bytes || known.per_cu < 1)
 				{
 					int per_cu = 0;
-					if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes) != hipSuccess || per_cu < 1)
+					hipError_t asked;
+					if constexpr (!SM)
+						asked = sub_chunk_items ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM, true>, static_cast<int>(block_threads), lds_bytes)
+												: hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM, false>, static_cast<int>(block_threads), lds_bytes);
+					else
+						asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes);
+					if (asked != hipSuccess || per_cu < 1)
 						per_cu = 4;
 					(void)hipGetLastError();
 					known.lds_bytes = lds_bytes;
@@ -1475,7 +1530,7 @@ namespace rt_hip
 				}
 				grid = dim3(std::min(grid.x, compute_units * static_cast<uint32_t>(known.per_cu)));
 			}
-			if constexpr (NS >= 0 && !SM) // (the sm table keeps whole chunks: one set of kernels fewer to build)
+			if constexpr (!SM) // (the sm table keeps whole chunks: one set of kernels fewer to build)
 			{
 				if (queue.halves)
 				{
@@ -1531,7 +1586,7 @@ namespace rt_hip
 		return samples_per_pixel >= 32u ? RT_HIP_KERNEL_STREAMED : RT_HIP_KERNEL_TILED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives)
 	{
 		queue_params q{};
 		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk; // K chunks per pixel
@@ -1543,6 +1598,34 @@ namespace rt_hip
 			// the sequence runs dry, large enough that the counter sees one atomic per wave every few trips
 			pixels_log2 = 0;
 			q.block_items = 8u;
+			// Sub-chunk items.  A trip of a big-scene wave costs the same with one lane holding a ray as with 64, and from the
+			// moment the launch-wide sequence runs dry every lane still owes the rest of its item: with whole chunks the
+			// last 10 % of config 5's launch ran on thinning waves (4.9 % of all wave-time after the waves' retirement alone,
+			// profiles/r03/config5_streamed/wave_tail_items_sparse.txt), and its 8-way share — 2.6 chunks per lane — took
+			// twice its share of the time.  Items may be ANY run of consecutive samples if every sample's VALUE is handed
+			// over instead of a chunk's sum (16 bytes per sample through HBM: nothing next to a scan of the scene per path
+			// segment) and the lane that brings a pixel's last item adds them up as the contract says.  How small: every item
+			// costs an arrival (an atomic in HBM: the device does ~0.66 G of them per second, profiles/r03/item_sweep.txt),
+			// which stays in the shadow of the tracing while samples-per-item x primitives >= 8192 — one sample per item from
+			// 8192 primitives upwards, eight at 1025.  Measured: config 5 5.55 -> 5.10 s, its 1/8 share 1203 -> 636 ms;
+			// 30 000 x 64 spp 1756 -> 1616; 10 000 x 32 spp 276 -> 244; 2 000 x 64 spp 96.4 -> 90.5; 1 025 x 64 spp 49.7 -> 47.1.
+			q.item_samples = sample_chunk;
+			if (half_chunks && samples_per_pixel > 1u && primitives)
+			{
+				uint32_t smallest = 1u;
+				while (smallest < sample_chunk && static_cast<uint64_t>(smallest) * primitives < 8192u)
+					smallest *= 2u;
+				// (a sample's slot is 16 bytes: frames whose samples would need more than 8 GiB keep whole chunks)
+				if (static_cast<uint64_t>(width) * local_rows * samples_per_pixel * 16u <= (8ull << 30))
+					q.item_samples = smallest;
+				if (half_chunks == 2 && q.item_samples == sample_chunk)
+					q.item_samples = sample_chunk / 2u;
+#ifdef RT_HIP_QUEUE_KNOBS
+				if (const char* knob = std::getenv("RT_HIP_ITEM_SAMPLES")) // experiment builds only (tools/gpu_item_sweep.py)
+					q.item_samples = static_cast<uint32_t>(std::atoi(knob));
+#endif
+				q.halves = q.item_samples < sample_chunk ? 1u : 0u;
+			}
 		}
 		else
 		{
@@ -1614,13 +1697,13 @@ namespace rt_hip
 		return q;
 	}
 
-	void rolling_buffer_bytes(const queue_params& queue, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes)
+	void rolling_buffer_bytes(const queue_params& queue, uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes)
 	{
 		item_sums_bytes = pixel_done_bytes = 0;
-		if (!big_scene || queue.chunks <= 1u) // one chunk per pixel: the lane that traced it writes the pixel
+		if (!big_scene || (queue.chunks <= 1u && !queue.halves)) // one chunk per pixel: the lane that traced it writes the pixel
 			return;
 		const size_t pixels = static_cast<size_t>(width) * local_rows;
-		item_sums_bytes = pixels * queue.chunks * 16u;
+		item_sums_bytes = queue.halves ? pixels * samples_per_pixel * 16u : pixels * queue.chunks * 16u;
 		pixel_done_bytes = pixels * sizeof(uint32_t);
 	}
 
@@ -1643,11 +1726,11 @@ namespace rt_hip
 		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags));
+		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes);
 
 		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
 		// the device keeps resident, and no more lanes than items
-		const uint64_t total_items = static_cast<uint64_t>(frame.width) * frame.local_rows * queue.chunks;
+		const uint64_t total_items = static_cast<uint64_t>(frame.width) * frame.local_rows * ((big_scene && queue.halves) ? (frame.samples_per_pixel + queue.item_samples - 1u) / queue.item_samples : queue.chunks);
 		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_items + block_threads - 1u) / block_threads))) // capped to the resident count at launch
 									: dim3((queue.tiles_x + 3u) / 4u, queue.tiles_y);
 		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * tile_slot_bytes(queue);

@@ -110,7 +110,9 @@ namespace rt_hip
 		uint32_t tile_w_log2;	   // a tile is 2^tile_w_log2 columns wide
 		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
 		uint32_t block_items;	   // big scenes: items a wave draws from the launch-wide sequence at a time
-		uint32_t halves;		   // small scenes, short launches: 1 = the work items are HALF chunks (8 samples), see render_queue
+		uint32_t halves;		   // short launches: 1 = the work items are smaller than a chunk (render_queue<.., HALF>): small scenes
+								   // half chunks; big scenes item_samples consecutive samples, every sample's value parked
+		uint32_t item_samples;	   // big scenes with halves: samples per work item (8, 4, 2 or 1)
 	};
 	// LDS floats per chunk of a tile: its sum — or, with half-chunks, the first half's partial sum and the second half's 8 x 3 sample values
 	constexpr uint32_t half_chunk_slot_floats = 3u + 3u * (sample_chunk / 2u);
@@ -121,7 +123,7 @@ namespace rt_hip
 	// `host_frame`: the packed pixels go to page-locked HOST memory (every row fragment of a tile is a PCIe write)
 	// `half_chunks`: 0 = whole chunks (the sm table's kernels have no half-chunk build; RT_HIP_FLAG_FORCE_WHOLE_CHUNKS),
 	// 1 = by the size of the launch, 2 = half chunks wherever the samples allow (RT_HIP_FLAG_FORCE_HALF_CHUNKS)
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks);
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives);
 	inline int half_chunk_choice(uint32_t flags)
 	{
 		if (flags & (RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_FORCE_WHOLE_CHUNKS))
@@ -133,7 +135,7 @@ namespace rt_hip
 
 	// What the big-scene kernels exchange chunk sums through (owned by the context, grown on demand):
 	//   item_sums   16 bytes per item of this rank's rows (a chunk sum on its way to the lane that folds the pixel);
-	//               not needed when a pixel is one chunk
+	//               not needed when a pixel is one chunk.  With sub-chunk items: 16 bytes per SAMPLE
 	//   pixel_done  one arrival counter per pixel; zero between launches (the folding lane puts it back)
 	struct rolling_buffers
 	{
@@ -141,7 +143,7 @@ namespace rt_hip
 		uint32_t* pixel_done = nullptr;
 	};
 	// bytes of the two buffers for a launch (0, 0 for the small-scene kernels)
-	void rolling_buffer_bytes(const queue_params& queue, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes);
+	void rolling_buffer_bytes(const queue_params& queue, uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, size_t& item_sums_bytes, size_t& pixel_done_bytes);
 
 	struct device_counters
 	{
@@ -173,12 +175,12 @@ namespace rt_hip
 			size_t lds_bytes = 0;
 			int per_cu = 0;
 		};
-		entry persistent[6]; // { tiled, streamed } x { mg, sm scatter table, fast arithmetic }
+		entry persistent[12]; // { tiled, streamed } x { mg, sm scatter table, fast arithmetic } x { whole chunks, sub-chunk items }
 		// one definition for both builds of kernels.hip (the parity contract and RT_HIP_FAST_BUILD), which are linked into
 		// one library: the build says which arithmetic it is through the argument (the fast build has no sm scatter table)
-		static constexpr unsigned slot(bool streamed, bool sm, bool fast_arithmetic)
+		static constexpr unsigned slot(bool streamed, bool sm, bool fast_arithmetic, bool sub_chunk_items)
 		{
-			return (streamed ? 3u : 0u) + (fast_arithmetic ? 2u : (sm ? 1u : 0u));
+			return (sub_chunk_items ? 6u : 0u) + (streamed ? 3u : 0u) + (fast_arithmetic ? 2u : (sm ? 1u : 0u));
 		}
 	};
 

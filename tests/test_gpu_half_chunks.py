@@ -88,3 +88,25 @@ def test_an_eighth_of_config_2_in_half_chunks_is_the_same_eighth(tracer):
                 n = min(8, height - y0)
                 assert np.array_equal(got[local : local + n], whole[y0 : y0 + n]), (rank, flags, stripe)
                 local += n
+
+
+@pytest.mark.parametrize("spp", [2, 5, 16, 17, 40, 70])
+@pytest.mark.parametrize("kernel", [capi.RT_HIP_FLAG_FORCE_STREAMED, capi.RT_HIP_FLAG_FORCE_TILED], ids=["streamed", "tiled"])
+def test_big_scene_kernels_hand_out_runs_of_samples_and_add_them_up_as_the_contract_says(tracer, kernel, spp):
+    """The rolling big-scene kernels with items smaller than a chunk: every sample's value travels through HBM on its own and
+    the lane that brings a pixel's last item adds them up — sixteen in sample order per chunk, chunks in chunk order.  The
+    launch code's own choice for a frame this small is one or two samples per item; forced: eight; and whole chunks."""
+    from tests.test_gpu_parity import _sphere_field
+
+    width, height = 40, 22
+    rng = np.random.default_rng(spp)
+    spheres, materials, camera = _sphere_field(rng, 1500)
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, [], materials, samples_per_pixel=spp, max_bounces=6, inverse_view_projection=ivp)
+    want, want_rgb, want_stats = oracle.render(pod, width, height, seed=7)
+    for flags in (0, HALF, WHOLE):
+        for _ in range(2):  # (the second launch finds the pixels' arrival counters as the first one left them: zero)
+            got, rgb, stats = tracer.render(pod, width, height, seed=7, flags=kernel | flags, want_rgb=True)
+            assert stats["kernel"] in ("streamed", "tiled")
+            assert np.array_equal(got, want) and same_bits(rgb, want_rgb), (spp, flags)
+            assert stats["segments"] == want_stats["segments"]
