@@ -2,7 +2,7 @@
 # Round 3, last visit: the whole GPU suite, the headline's profile, traffic counters of the other configurations, every
 # bench line that DESIGN.md quotes.
 set -o pipefail
-mkdir -p gpurun_out/z
+mkdir -p gpurun_out/z; rm -rf gpurun_out/z/*
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout -k 10 1000 python -m pytest tests -x -q -m gpu > gpurun_out/z/pytest_gpu.txt 2>&1
 echo "GPU suite: rc $?" | tee gpurun_out/z/status.txt
