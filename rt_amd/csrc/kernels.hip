@@ -1577,13 +1577,17 @@ namespace rt_hip
 		// (the scalar-register kernel knows rt's camera only — a matrix whose w varies over the frame takes the LDS kernel)
 		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && uniform_w && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
-		if (primitives <= resident_max_primitives)
+		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
+		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against
+		// 50.9 ms; 512: 26.0 against 25.0 — profiles/r03/midsize_kernels.txt).
+		if (primitives <= resident_max_primitives && ((flags & RT_HIP_FLAG_FORCE_RESIDENT) || primitives <= streamed_from_primitives))
 			return RT_HIP_KERNEL_RESIDENT;
-		// big scenes: the scalar-streamed kernel (no staging, no barriers) wins from about 32 samples per pixel upwards —
-		// 100 000 spheres x 64 spp: 6.46 s against 6.90-7.06 s; 10 000 x 32: 337 against 345 ms; 2 000 x 64: 98 against 108 ms —
-		// and loses 2 % at 8 spp, where a wave holds one item per lane and the tiled kernel's shared staging pays
-		// (profiles/r01/streamed_vs_tiled.txt, profiles/r02/config5_full_size.txt)
-		return samples_per_pixel >= 32u ? RT_HIP_KERNEL_STREAMED : RT_HIP_KERNEL_TILED;
+		// Big scenes: the scalar-streamed kernel (no staging, no barriers).  Rounds 1-2 chose the LDS-tiled kernel below
+		// 32 samples per pixel, where it was 2 % ahead; since the group prefetch, the cooperative scan of sparse waves and
+		// the one-sample items the streamed kernel is 10-30 % ahead at every sample count from 1 to 24 and every size from
+		// 1 100 to 100 000 spheres (profiles/r03/tiled_vs_streamed.txt).  The tiled kernel stays behind its flag.
+		(void)samples_per_pixel;
+		return RT_HIP_KERNEL_STREAMED;
 	}
 
 	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives)

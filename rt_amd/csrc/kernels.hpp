@@ -165,6 +165,7 @@ namespace rt_hip
 	};
 
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
+	constexpr uint32_t streamed_from_primitives = 704; // ... which the launch code prefers up to this many
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
 	// what a context remembers between launches: workgroups per CU that stay resident, for the persistent (big-scene) kernels

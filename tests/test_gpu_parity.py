@@ -148,12 +148,14 @@ def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, boun
     assert stats["primary_samples"] == width * height * spp
     assert stats["sphere_tests"] == want_stats["segments"] * pod.n_spheres
     primitives = pod.n_spheres + pod.n_planes
-    if flags == FORCE_STREAMED:
-        expected_kernel = "streamed"
-    elif flags == FORCE_TILED or primitives > 1024:
+    if flags == FORCE_TILED:
         expected_kernel = "tiled"
+    elif flags == FORCE_STREAMED or primitives > 1024:
+        expected_kernel = "streamed"  # (every big scene, whatever its sample count: profiles/r03/tiled_vs_streamed.txt)
     elif flags == 0 and pod.n_planes == 0 and 1 <= pod.n_spheres <= 8:
         expected_kernel = "small"
+    elif flags == 0 and primitives > 704:
+        expected_kernel = "streamed"  # (the resident kernel holds up to 1024 primitives; the launch code prefers it up to 704)
     else:
         expected_kernel = "resident"
     assert stats["kernel"] == expected_kernel
@@ -427,16 +429,17 @@ def test_config4_basic_4k_tile_split(tracer):
     check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(spp), 3840, 2160, seed=1, oracle_world=16)
 
 
-def test_config5_synthetic_100k_tiled(tracer):
-    """BASELINE config 5's scene (100 000 spheres, LDS-tiled kernel) at a size the oracle finishes in seconds,
-    bit-exact; the full 1920x1080x64 frame is a bench configuration (minutes of oracle time per stripe)."""
+@pytest.mark.parametrize("flags,kernel", [(0, "streamed"), (FORCE_TILED, "tiled")], ids=["auto", "tiled"])
+def test_config5_synthetic_100k_small_frame(tracer, flags, kernel):
+    """BASELINE config 5's scene (100 000 spheres) at a size the oracle finishes in seconds, bit-exact, through the kernel the
+    launch code picks and through the LDS-tiled one; the full 1920x1080x64 frame is checked stripe-wise below."""
     scene = rt_amd.Scene.named("synthetic-100k").set_sampling(1)
     width, height = 64, 36
     pod = scene.describe(width, height)
     assert pod.n_spheres == 100000
-    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=1, want_rgb=True)
+    got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=1, flags=flags, want_rgb=True)
     want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=1)
-    assert stats["kernel"] == "tiled"
+    assert stats["kernel"] == kernel
     assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "synthetic-100k")
     assert stats["segments"] == want_stats["segments"]
 
