@@ -1649,10 +1649,14 @@ namespace rt_hip
 		// a rank's 1/8 share of a 64-spp frame holds two per lane and took 0.21 ms for 0.09 ms of work; with 8-sample items
 		// 0.13-0.14 (profiles/r03/chunk_probe.txt: 1/4 share -11 %, nothing from eight chunks per lane upwards, where the
 		// parking would only cost).  64 half-chunks per wave, one per lane; tiles of at least four pixels.
+		// (Not for pixels of ONE chunk, forced aside: their tiles would hold half as many pixels and the wave's fold — a
+		// division and three square roots per pixel — runs on half its lanes: 1080p x 16 spp 0.345 against 0.323 ms.  Between
+		// four and seven chunks per lane the gain fades: 800 x 600 x 64 spp -16 %, 1280 x 720 x 64 spp +16 %;
+		// profiles/r03/half_threshold.txt.)
 		if (half_chunks && !big_scene && samples_per_pixel > sample_chunk / 2u && q.chunks <= 16u)
 		{
 			constexpr uint64_t resident_lanes = 256ull * 4ull * 8ull * 64ull; // an MI355X at 8 waves per SIMD
-			if (half_chunks == 2 || static_cast<uint64_t>(width) * local_rows * q.chunks < 6ull * resident_lanes)
+			if (half_chunks == 2 || (q.chunks >= 2u && static_cast<uint64_t>(width) * local_rows * q.chunks < 5ull * resident_lanes))
 			{
 				q.halves = 1u;
 				pixels_log2 = 2u;
