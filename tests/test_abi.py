@@ -72,6 +72,12 @@ def test_null_arguments_are_refused_not_crashed():
     assert lib.rt_hip_scene_upload(None, None) == 1
     assert lib.rt_hip_render(None, None, None, 4, 4, 0, 0, None, None) == 1
     assert lib.rt_hip_stats_fetch(None, None) == 1
+    assert lib.rt_hip_join_frame_group(None, 0, 1, b"/x", 10) == 1 and b"NULL" in lib.rt_hip_last_error()
+    assert lib.rt_hip_join_ranks(None, 0, 1, (C.c_char * 128)(), 10) == 1
+    assert lib.rt_hip_comm_info(None, 0, None, None, None, None) == 1
+    assert lib.rt_hip_phases_fetch(None, None) == 1
+    assert lib.rt_hip_scene_check(None, None) == 1
+    lib.rt_hip_forget_frame(None)  # no-op
     lib.rt_hip_destroy(None)  # no-op
 
 
