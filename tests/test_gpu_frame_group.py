@@ -97,6 +97,20 @@ def test_a_group_of_one_and_a_buffer_mapped_anew(tmp_path):
     assert all(np.array_equal(np.load(out / f"frame_{f}.npy"), want[f]) for f in want)
 
 
+def test_more_ranks_than_stripes_and_rows_that_straddle_pages(tmp_path):
+    """20 rows are three stripes: the fourth rank owns nothing and still takes part in every frame; 50 pixels a row put no
+    stripe boundary on a page boundary (the placement leaves such pages where they are)."""
+    width, height, spp = 50, 20, 3
+    results, out = run_group(tmp_path, 4, width, height, spp, frames=2)
+    assert all(r["error"] is None and r["frames_done"] == 2 for r in results), results
+    pod = rt_amd.Scene.named("basic").set_sampling(spp).describe(width, height)
+    for f in (1, 2):
+        want, _, want_stats = oracle.render(pod, width, height, seed=f, want_rgb=False)
+        assert np.array_equal(np.load(out / f"frame_{f}.npy"), want)
+    assert [m["primary_samples"] for m in results[0]["member_stats"]] == [width * 8 * spp, width * 8 * spp, width * 4 * spp, 0]
+    assert results[3]["stats"]["segments"] == want_stats["segments"]  # (every rank reports the whole frame)
+
+
 def test_the_preview_and_the_sm_material_table_go_through_a_frame_group_too(tmp_path, tracer):
     from rt_amd import capi
 
