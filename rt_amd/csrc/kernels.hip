@@ -1629,6 +1629,10 @@ namespace rt_hip
 					q.item_samples = static_cast<uint32_t>(std::atoi(knob));
 #endif
 				q.halves = q.item_samples < sample_chunk ? 1u : 0u;
+#ifdef RT_HIP_QUEUE_KNOBS
+				if (const char* knob = std::getenv("RT_HIP_BLOCK_ITEMS"))
+					q.block_items = static_cast<uint32_t>(std::atoi(knob));
+#endif
 			}
 		}
 		else
