@@ -1690,7 +1690,9 @@ namespace rt_hip
 			const uint64_t pixels = static_cast<uint64_t>(width) * local_rows;
 			if (pixels_log2 == 3u && (q.chunks << 4u) <= 256u && (pixels >> 4u) >= 49152u)
 				q.pixels_log2 = pixels_log2 = 4u;
-			q.tile_w_log2 = (pixels_log2 == 4u && q.chunks == 16u) ? 3u : std::min(pixels_log2, 4u);
+			// (16 pixels at 256 spp: 8 x 2 for the 1..4-sphere kernels — basic.toml 2.639 against 2.664 ms as 16 x 1 — and 16 x 1
+			// for the 5..8-sphere and the resident ones — dielectric.toml 3.011 against 3.040 as 8 x 2; tile_sweep_drop_in.txt)
+			q.tile_w_log2 = (pixels_log2 == 4u && q.chunks == 16u && primitives < 5u) ? 3u : std::min(pixels_log2, 4u);
 		}
 #ifdef RT_HIP_QUEUE_KNOBS
 		// experiment builds only (tools/gpu_tile_shapes.py): tile size and width from the environment, per launch
