@@ -298,7 +298,8 @@ rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char
  *       that process's mapping of the one shared buffer (the library checks all of this: a rank called with other
  *       arguments, or whose `pixels` is not the memory rank 0 renders into, fails the frame on every rank).  Returns on
  *       every rank when the WHOLE frame is in the buffer.  RT_HIP_FLAG_PERSISTENT_FRAME is implied; rgb_f32 must be NULL.
- *       `stats` / rt_hip_stats_fetch give the whole frame (counts summed over the ranks, the slowest rank's kernel time),
+ *       `stats` / rt_hip_stats_fetch give the whole frame (counts summed over the ranks, the slowest rank's kernel time;
+ *       a rank that was called without `stats` and without RT_HIP_FLAG_STATS contributes zeros),
  *       rt_hip_member_stats(ctx, r, ..) / rt_hip_member_device(ctx, r, ..) rank r's share and device, for any r < world.
  * A rank that fails, leaves (rt_hip_destroy) or stays away longer than RT_HIP_GROUP_DEADLINE_MS (default 120 000) breaks
  * the group: every rank's current and later rt_hip_render returns an error naming the rank and the reason; the renderer
