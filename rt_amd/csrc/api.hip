@@ -1298,7 +1298,7 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
-		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes);
+		const queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes, variant == RT_HIP_KERNEL_STREAMED && ctx->scene.n_spheres >= sparse_launch_min_spheres);
 		// small scenes: a pixel's chunk sums (one per 16 samples) are parked in LDS until the pixel is complete
 		const uint64_t slot_bytes = big_scene ? 0u : 4ull * tile_slot_bytes(queue);
 		if (slot_bytes > 48u * 1024u)

@@ -240,8 +240,8 @@ namespace rt_hip
 		// The one thing a minimum cannot reproduce is a NaN distance (a degenerate ray), which the sequential rule lets
 		// in and then never displaces consistently: if any lane meets one, the ray is reported as not scanned and goes
 		// through the sequential scan.  The per-sphere arithmetic is finish_sphere's, bit for bit.
-		constexpr uint32_t sparse_wave_rays = 8;	 // a wave holding at most this many rays scans together
-		constexpr uint32_t sparse_min_spheres = 1024; // (below that a sequential scan is a few microseconds anyway)
+		[[maybe_unused]] constexpr uint32_t sparse_wave_rays = 8;	 // a wave holding at most this many rays scans together
+		constexpr uint32_t sparse_min_spheres = sparse_launch_min_spheres; // (below that a sequential scan is a few microseconds anyway)
 
 		__device__ __forceinline__ void test_sphere_alone(candidate& best, bool& met_nan, vec3 o, vec3 d, float4 s, uint32_t index)
 		{
@@ -546,7 +546,7 @@ namespace rt_hip
 			const unsigned long long total_items = static_cast<unsigned long long>(p.width) * p.local_rows * items_per_pixel;
 			unsigned long long block_next = 0, block_end = 0; // [block_next, block_end): not yet given to a lane
 			unsigned long long prefetched = 0;				  // first item of the block after that
-			uint32_t prefetched_count = 64u;				  // (the first block is a whole wave's worth: every lane starts at once)
+			uint32_t prefetched_count = ROLLING ? min(64u, q.lane_cap) : 64u; // (the first block is a whole wave's worth — or the wave's cap: every lane that may hold a ray starts at once)
 			bool dry = false;								  // the launch-wide sequence has run out
 			if (ROLLING)
 				prefetched = fetch_items(counters, prefetched_count);
@@ -817,7 +817,7 @@ namespace rt_hip
 				if (sparse_waves && NS == -2 && s.n_spheres >= sparse_min_spheres)
 				{
 					unsigned long long holders = __builtin_amdgcn_ballot_w64(tracing);
-					if (holders != 0 && static_cast<uint32_t>(__builtin_popcountll(holders)) <= sparse_wave_rays)
+					if (holders != 0 && static_cast<uint32_t>(__builtin_popcountll(holders)) <= q.sparse_rays)
 					{
 						while (holders != 0) // (wave-uniform)
 						{
@@ -991,7 +991,12 @@ namespace rt_hip
 				if (ROLLING && asking != 0)
 				{
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
-					const uint32_t want = static_cast<uint32_t>(__builtin_popcountll(asking));
+					uint32_t want = static_cast<uint32_t>(__builtin_popcountll(asking));
+					if (q.lane_cap < 64u) // (wave-uniform) a sparse launch: this wave holds at most lane_cap rays, see choose_queue
+					{
+						const uint32_t holding = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mode == lane_trace || mode == lane_restart)));
+						want = min(want, q.lane_cap > holding ? q.lane_cap - holding : 0u);
+					}
 					uint32_t served = 0; // asking lanes given an item so far, in rank order
 					while (served < want)
 					{
@@ -1590,7 +1595,7 @@ namespace rt_hip
 		return RT_HIP_KERNEL_STREAMED;
 	}
 
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives)
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives, bool sparse_launch)
 	{
 		queue_params q{};
 		q.chunks = (samples_per_pixel + sample_chunk - 1u) / sample_chunk; // K chunks per pixel
@@ -1602,6 +1607,8 @@ namespace rt_hip
 			// the sequence runs dry, large enough that the counter sees one atomic per wave every few trips
 			pixels_log2 = 0;
 			q.block_items = 8u;
+			q.lane_cap = 64u;
+			q.sparse_rays = sparse_wave_rays;
 			// Sub-chunk items.  A trip of a big-scene wave costs the same with one lane holding a ray as with 64, and from the
 			// moment the launch-wide sequence runs dry every lane still owes the rest of its item: with whole chunks the
 			// last 10 % of config 5's launch ran on thinning waves (4.9 % of all wave-time after the waves' retirement alone,
@@ -1633,6 +1640,24 @@ namespace rt_hip
 				if (const char* knob = std::getenv("RT_HIP_BLOCK_ITEMS"))
 					q.block_items = static_cast<uint32_t>(std::atoi(knob));
 #endif
+			}
+			// Sparse launches of the streamed kernel.  A trip costs one sequential scan of the scene whether the wave holds 64
+			// rays or one; the cooperative scan (scan_spheres_together) costs a wave about 1/40 of that PER RAY.  At the end of a
+			// full launch, where the device is busy, it pays up to 8 rays (sparse_wave_rays: an A/B of round 3); in a launch
+			// that cannot fill the device at all — fewer work items than 32 per wave it can hold — it pays all the way:
+			// the launch is spread THIN, every wave taking at most ceil(items / waves) rays at a time, and scans
+			// cooperatively throughout (profiles/r03/sparse_launch.txt).
+			if (sparse_launch)
+			{
+				constexpr uint64_t launch_waves = 256ull * 4ull * 5ull;
+				const uint64_t items = static_cast<uint64_t>(width) * local_rows * (q.halves ? (samples_per_pixel + q.item_samples - 1u) / q.item_samples : q.chunks);
+				const uint64_t per_wave = (items + launch_waves - 1u) / launch_waves;
+				if (per_wave <= 32u)
+				{
+					q.lane_cap = static_cast<uint32_t>(std::max<uint64_t>(per_wave, 1u));
+					q.block_items = std::min(q.block_items, q.lane_cap);
+					q.sparse_rays = std::max(q.sparse_rays, q.lane_cap);
+				}
 			}
 		}
 		else
@@ -1740,12 +1765,14 @@ namespace rt_hip
 		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
-		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes);
+		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes,
+												variant == RT_HIP_KERNEL_STREAMED && scene.n_spheres >= sparse_launch_min_spheres);
 
 		// small scenes: one wave per tile, four tiles side by side per workgroup.  Big scenes: a persistent launch — what
 		// the device keeps resident, and no more lanes than items
 		const uint64_t total_items = static_cast<uint64_t>(frame.width) * frame.local_rows * ((big_scene && queue.halves) ? (frame.samples_per_pixel + queue.item_samples - 1u) / queue.item_samples : queue.chunks);
-		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_items + block_threads - 1u) / block_threads))) // capped to the resident count at launch
+		const uint64_t items_per_workgroup = big_scene ? static_cast<uint64_t>(block_threads / 64u) * queue.lane_cap : block_threads; // (a sparse launch: lane_cap rays per wave)
+		const dim3 grid = big_scene ? dim3(static_cast<uint32_t>(std::min<uint64_t>(0x7FFFFFFFull, (total_items + items_per_workgroup - 1u) / items_per_workgroup))) // capped to the resident count at launch
 									: dim3((queue.tiles_x + 3u) / 4u, queue.tiles_y);
 		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * tile_slot_bytes(queue);
 		if (variant == RT_HIP_KERNEL_SMALL)

@@ -110,6 +110,8 @@ namespace rt_hip
 		uint32_t tile_w_log2;	   // a tile is 2^tile_w_log2 columns wide
 		uint32_t tiles_x, tiles_y; // tiles across / down this rank's rows
 		uint32_t block_items;	   // big scenes: items a wave draws from the launch-wide sequence at a time
+		uint32_t lane_cap;		   // big scenes: rays a wave holds at most (64 = all lanes; less in sparse launches of the streamed kernel)
+		uint32_t sparse_rays;	   // streamed kernel: a wave holding at most this many rays scans cooperatively
 		uint32_t halves;		   // short launches: 1 = the work items are smaller than a chunk (render_queue<.., HALF>): small scenes
 								   // half chunks; big scenes item_samples consecutive samples, every sample's value parked
 		uint32_t item_samples;	   // big scenes with halves: samples per work item (8, 4, 2 or 1)
@@ -123,7 +125,8 @@ namespace rt_hip
 	// `host_frame`: the packed pixels go to page-locked HOST memory (every row fragment of a tile is a PCIe write)
 	// `half_chunks`: 0 = whole chunks (the sm table's kernels have no half-chunk build; RT_HIP_FLAG_FORCE_WHOLE_CHUNKS),
 	// 1 = by the size of the launch, 2 = half chunks wherever the samples allow (RT_HIP_FLAG_FORCE_HALF_CHUNKS)
-	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives);
+	queue_params choose_queue(uint32_t samples_per_pixel, uint32_t width, uint32_t local_rows, bool big_scene, bool host_frame, int half_chunks, uint32_t primitives, bool sparse_launch);
+	constexpr uint32_t sparse_launch_min_spheres = 1024; // the streamed kernel's cooperative scan (a wave with a handful of rays) exists from here
 	inline int half_chunk_choice(uint32_t flags)
 	{
 		if (flags & (RT_HIP_FLAG_SM_MATERIALS | RT_HIP_FLAG_FORCE_WHOLE_CHUNKS))
