@@ -10,36 +10,53 @@ LIBDIR   := rt_amd/lib
 HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wextra -Wno-unused-parameter
 HOSTFLAGS:= -std=c++20 -O2 -fPIC -Wall -Wextra
 
-HIP_SRC  := rt_amd/csrc/kernels.hip rt_amd/csrc/api.hip
-HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp rt_amd/csrc/frame_group.hpp include/rt_hip.h
+HIPFLAGS += -fvisibility=hidden
+API_UNITS := context scene frame render multi group
+HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp rt_amd/csrc/scan.hpp rt_amd/csrc/frame_group.hpp rt_amd/csrc/delivery.hpp rt_amd/csrc/internal.hpp include/rt_hip.h
 HOST_SRC := rt_amd/host/host_capi.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp
 HOST_HDR := $(wildcard rt_amd/host/*.hpp) rt_amd/host/host_capi.h rt_amd/host/named_colours.inc include/rt_hip.h
 
-all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_host.so rt_amd/bin/rt_headless oracle
+all: $(LIBDIR)/librt_hip.so $(LIBDIR)/librt_hip_kat.so $(LIBDIR)/librt_host.so rt_amd/bin/rt_headless oracle
 
 # kernels.hip is compiled twice: the parity contract (contraction off), and RT_HIP_FLAG_FAST's arithmetic
 # (-DRT_HIP_FAST_BUILD -ffp-contract=fast: only launch_render_fast comes out of that one)
 FASTFLAGS := $(filter-out -ffp-contract=off,$(HIPFLAGS)) -ffp-contract=fast -DRT_HIP_FAST_BUILD
 OBJDIR   := build/obj$(NAME)
+HIP_OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(API_UNITS:%=$(OBJDIR)/%.o) $(OBJDIR)/delivery.o
 
-$(LIBDIR)/librt_hip.so: $(HIP_SRC) $(HIP_HDR)
-	@mkdir -p $(LIBDIR) $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
-	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl -lpthread
+$(OBJDIR)/kernels.o: rt_amd/csrc/kernels.hip $(HIP_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $< -o $@
+$(OBJDIR)/kernels_fast.o: rt_amd/csrc/kernels.hip $(HIP_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(FASTFLAGS) $(DEFS) -c $< -o $@
+$(OBJDIR)/%.o: rt_amd/csrc/%.hip $(HIP_HDR)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) $(DEFS) -c $< -o $@
+# the pixel carrier is plain C++17 (no HIP): the same source is built into tests/native/pixel_carrier_test on the CPU
+$(OBJDIR)/delivery.o: rt_amd/csrc/delivery.cpp rt_amd/csrc/delivery.hpp
+	@mkdir -p $(OBJDIR)
+	$(CXX) -std=c++17 -O2 -fPIC -fvisibility=hidden -Wall -Wextra -c $< -o $@
+
+# the product: exports the C entry points of include/rt_hip.h and nothing else
+$(LIBDIR)/librt_hip.so: $(HIP_OBJS)
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(HIP_OBJS) -L/opt/rocm/lib -lrccl -lpthread
+
+# test-only: the known-answer entry points of include/rt_hip_kat.h (never shipped; loads next to librt_hip.so)
+$(LIBDIR)/librt_hip_kat.so: $(OBJDIR)/kat.o $(LIBDIR)/librt_hip.so
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(OBJDIR)/kat.o -L$(LIBDIR) -lrt_hip -Wl,-rpath,'$$ORIGIN' -L/opt/rocm/lib -lrccl
+$(OBJDIR)/kat.o: include/rt_hip_kat.h
 
 $(LIBDIR)/librt_host.so: $(HOST_SRC) $(HOST_HDR)
 	@mkdir -p $(LIBDIR)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRC)
 
 # experiment builds for tools/gpu_ab.py: make variant NAME=x DEFS="-DRT_HIP_SOMETHING=1" -> rt_amd/lib/librt_hip_x.so
-variant:
-	@mkdir -p $(LIBDIR) $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels.o
-	$(HIPCC) $(FASTFLAGS) $(DEFS) -c rt_amd/csrc/kernels.hip -o $(OBJDIR)/kernels_fast.o
-	$(HIPCC) $(HIPFLAGS) $(DEFS) -c rt_amd/csrc/api.hip -o $(OBJDIR)/api.o
-	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(OBJDIR)/kernels.o $(OBJDIR)/kernels_fast.o $(OBJDIR)/api.o -L/opt/rocm/lib -lrccl -lpthread
+# (objects under build/obj<NAME>; an experiment library carries the known-answer and debug entry points itself)
+variant: $(HIP_OBJS) $(OBJDIR)/kat.o
+	@mkdir -p $(LIBDIR)
+	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $(LIBDIR)/librt_hip_$(NAME).so $(HIP_OBJS) $(OBJDIR)/kat.o -L/opt/rocm/lib -lrccl -lpthread
 
 # windowless driver: the registry, the hip_ray_tracer plug-in and the scene loader, linked against the C ABI only
 HEADLESS_SRC := rt_amd/host/main.cpp rt_amd/host/hip_ray_tracer.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp

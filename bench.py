@@ -136,6 +136,7 @@ def main() -> None:
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` (default) = the torch form first, then the module's own renderer (see the docstring), `value` from the latter when it validated; `torch` = the torch form only")
     ap.add_argument("--library-deadline-s", type=float, default=0.0, help="watchdog of the library form under torchrun: seconds it may take in all before the torch form's line is printed instead (0 = 120 s + 50 x what the torch form took)")
     ap.add_argument("--direct-frame", action="store_true", help="single-process N > 1 only: RT_HIP_MULTI_DIRECT_FRAME — no gather, every GPU stores its pixels straight into the page-locked back buffer")
+    ap.add_argument("--locked-frame", action="store_true", help="single-process only: time the opt-in zero-copy mode (RT_HIP_FLAG_PERSISTENT_FRAME: the caller's buffer itself page-locked and mapped) as `value` instead of the default delivery through the module's own frame")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
     args = ap.parse_args()
 
@@ -244,6 +245,7 @@ def main() -> None:
                 "arithmetic": "contract v3-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v3 (bit-exact against the oracle)",
                 "parallelism": transport_text,
                 "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight if args.gather == "torch" else 1),
+                "frame_mode": ("locked: the caller's back buffer page-locked and mapped, kernels store straight into it (opt-in)" if args.locked_frame else "default: kernels store into the module's own page-locked frame, host threads carry the pixels into the caller's pageable back buffer while the frame is traced") if single_process else "see parallelism",
                 "clock_settle_ms": args.settle_ms,
             },
             "roofline": roofline,
@@ -265,7 +267,10 @@ def main() -> None:
         else:
             tracer = rt_amd.HipRayTracer(devices=list(range(n_gpus)), direct_frame=args.direct_frame)
         back_buffer = np.zeros((args.height, args.width), dtype=np.uint32)  # rt keeps one back buffer per window size
-        render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
+        # the call as shim/hip_ray_tracer.cpp makes it: NO frame flag — the kernels store into the module's own page-locked
+        # frame and its host threads carry the pixels into `back_buffer` (plain pageable memory) while the frame is traced.
+        # --locked-frame times the opt-in zero-copy mode instead (RT_HIP_FLAG_PERSISTENT_FRAME; side key `locked_frame` otherwise)
+        render_flags = flags | (capi.RT_HIP_FLAG_PERSISTENT_FRAME if args.locked_frame else 0)
 
         def step():
             return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
@@ -315,6 +320,20 @@ def main() -> None:
                 tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer, stats=False)
             per_frame = (time.perf_counter() - t1) / args.steps
             plug_in_call = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "rt_hip_render with stats == NULL, as shim/hip_ray_tracer.cpp calls it: no timing events, no counter traffic (the timed steps above keep them, for the roofline's kernel time)"}
+            # side figure: the other frame mode (default: the opt-in zero-copy mode; with --locked-frame: the default delivery)
+            other_flags = flags | (0 if args.locked_frame else capi.RT_HIP_FLAG_PERSISTENT_FRAME)
+            other_buffer = np.zeros((args.height, args.width), dtype=np.uint32)
+            for _ in range(3):
+                tracer.render(pod, args.width, args.height, seed=args.seed, flags=other_flags, out=other_buffer, stats=False)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tracer.render(pod, args.width, args.height, seed=args.seed, flags=other_flags, out=other_buffer, stats=False)
+            per_frame = (time.perf_counter() - t1) / args.steps
+            same_frame = bool(np.array_equal(other_buffer, back_buffer))
+            tracer.forget_frame()
+            extras["other_frame_mode"] = {"mode": "default (module-owned frame + host carrier threads)" if args.locked_frame else "locked (RT_HIP_FLAG_PERSISTENT_FRAME: the caller's buffer page-locked and mapped, zero copy; opt-in)",
+                                          "ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "vs_plug_in_call_ms": round(per_frame * 1e3 - plug_in_call["ms_per_step"], 4), "same_frame": same_frame,
+                                          "what": "rt_hip_render with stats == NULL in the other frame mode, same scene and seed"}
             # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
             frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
             stream = torch.cuda.current_stream().cuda_stream

@@ -25,7 +25,15 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 5u
+#define RT_HIP_ABI_VERSION 5u /* frozen: additions only (round 4 added rt_hip_live_frame_locks; the known-answer hooks of
+                               * rounds 1-3 moved to the test-only library, include/rt_hip_kat.h) */
+
+/* librt_hip.so is built with hidden visibility: these entry points are ALL it exports. */
+#if defined(__GNUC__)
+#define RT_HIP_API __attribute__((visibility("default")))
+#else
+#define RT_HIP_API
+#endif
 
 typedef enum rt_hip_status
 {
@@ -161,14 +169,17 @@ enum
 	RT_HIP_FLAG_FORCE_TILED = 1u << 0,
 	/* force the LDS-resident kernel for scenes that would take the scalar-register one (testing) */
 	RT_HIP_FLAG_FORCE_RESIDENT = 1u << 1,
-	/* rt_hip_render only: the caller promises that `pixels_rgba8888` stays allocated, at this address and size, until
-	 * the next rt_hip_render call on this context, rt_hip_forget_frame or rt_hip_destroy — as rt's back buffer does (one
-	 * image per window size, reference src/window.cpp:61-64, src/back_buffer.cpp).  The module then page-locks the
-	 * buffer once and maps it into the GPU's address space: a single-GPU context stores every finished pixel straight
-	 * into it while the rest of the frame is still being traced (no read-back step at all), a multi-GPU context copies
-	 * the assembled frame with one DMA.  Without the flag the buffer is treated as ordinary pageable memory.
-	 * A caller that frees the buffer and may get the same address back from its allocator before the next frame calls
-	 * rt_hip_forget_frame() in between (the page-lock would otherwise still hold the old pages). */
+	/* rt_hip_render only, OPT-IN: zero-copy delivery.  By default (flag absent) the kernels store finished pixels into a
+	 * page-locked frame the MODULE owns and host threads carry them on into `pixels_rgba8888` while the frame is still being
+	 * traced: the caller's buffer is plain memory to the module, touched only by CPU stores inside the call, and may be
+	 * freed, re-created or recycled at will between two calls (what rt does on every resize, reference src/window.cpp:198-203).
+	 * WITH the flag the caller promises that `pixels_rgba8888` stays allocated, at this address and size, until the next
+	 * rt_hip_render call on this context with another buffer, rt_hip_forget_frame or rt_hip_destroy.  The module then
+	 * page-locks the CALLER's buffer once and maps it into the GPU's address space: the kernels store every finished pixel
+	 * straight into it and no second copy of the frame exists (a few tens of microseconds less per 1080p frame).  A caller
+	 * that frees the buffer and may get the same address back from its allocator before the next frame MUST call
+	 * rt_hip_forget_frame() in between: a mapping re-created under a live page-lock is a GPU memory fault
+	 * (INTEGRATION.md §3). */
 	RT_HIP_FLAG_PERSISTENT_FRAME = 1u << 2,
 	/* shade with sm_ray_tracer's scatter table (reference src/renderers/sm_ray_tracer.cpp:221-236) instead of
 	 * mg_ray_tracer's: dielectric, air, vacuum, water and ice refract/reflect through dielectric_scatter (:181-219),
@@ -208,21 +219,21 @@ typedef struct rt_hip_ctx rt_hip_ctx;
 
 /* ---- library ---------------------------------------------------------------------------------------------------- */
 
-uint32_t rt_hip_abi_version(void);
+RT_HIP_API uint32_t rt_hip_abi_version(void);
 
 /* Message for the most recent failure on the calling thread ("" if none).  Never NULL. */
-const char* rt_hip_last_error(void);
+RT_HIP_API const char* rt_hip_last_error(void);
 
 /* Number of visible HIP devices.  Replaces nothing in the reference (CPU-only). */
-rt_hip_status rt_hip_device_count(int* count);
+RT_HIP_API rt_hip_status rt_hip_device_count(int* count);
 
 /* ---- context ---------------------------------------------------------------------------------------------------- */
 
 /* One context per GPU per renderer instance; owns the device copy of the scene, the stats block and
  * staging buffers.  Mirrors the lifetime of a renderer object in the reference: created by
  * description::create (src/renderer.hpp:39), destroyed through the virtual destructor (src/renderer.hpp:13). */
-rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device);
-void rt_hip_destroy(rt_hip_ctx* ctx);
+RT_HIP_API rt_hip_status rt_hip_create(rt_hip_ctx** out_ctx, int device);
+RT_HIP_API void rt_hip_destroy(rt_hip_ctx* ctx);
 
 /*
  * One renderer over SEVERAL GPUs of this process — what lets the reference's single blocking
@@ -254,7 +265,7 @@ enum
 	 * mean, take the gathered way.) */
 	RT_HIP_MULTI_DIRECT_FRAME = 1u << 1
 };
-rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags);
+RT_HIP_API rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int n_devices, uint32_t multi_flags);
 
 /*
  * The same renderer with ONE PROCESS PER GPU (how `torchrun` launches a job): every process creates one rank of it.
@@ -267,8 +278,8 @@ rt_hip_status rt_hip_create_multi(rt_hip_ctx** out_ctx, const int* devices, int 
  * rgb_f32 must be NULL or non-NULL on all ranks alike.  Nothing in the reference corresponds (it is one process).
  */
 #define RT_HIP_UNIQUE_ID_BYTES 128
-rt_hip_status rt_hip_unique_id(char out_id[RT_HIP_UNIQUE_ID_BYTES]);
-rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES]);
+RT_HIP_API rt_hip_status rt_hip_unique_id(char out_id[RT_HIP_UNIQUE_ID_BYTES]);
+RT_HIP_API rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES]);
 /*
  * rt_hip_create_rank in two halves, so that the part that can fail on ONE rank alone — no such device, not a gfx950, out
  * of memory — is over before anything collective starts (a rank that fails inside rt_hip_create_rank leaves the others
@@ -280,7 +291,7 @@ rt_hip_status rt_hip_create_rank(rt_hip_ctx** out_ctx, int device, int rank, int
  * environment, else 120 000) and then gives up with RT_HIP_TIMEOUT; the context stays a valid single-GPU context, which the
  * caller may use or destroy.  On success the context is what rt_hip_create_rank returns.
  */
-rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES], uint32_t timeout_ms);
+RT_HIP_API rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char id[RT_HIP_UNIQUE_ID_BYTES], uint32_t timeout_ms);
 
 /*
  * ONE PROCESS PER GPU WITHOUT AN EXCHANGE STEP — what RT_HIP_MULTI_DIRECT_FRAME is for one process, for `torchrun`-style
@@ -305,7 +316,7 @@ rt_hip_status rt_hip_join_ranks(rt_hip_ctx* ctx, int rank, int world, const char
  * the group: every rank's current and later rt_hip_render returns an error naming the rank and the reason; the renderer
  * is then destroyed and made anew.  Nothing in the reference corresponds (it is one process, one thread pool).
  */
-rt_hip_status rt_hip_join_frame_group(rt_hip_ctx* ctx, int rank, int world, const char* name, uint32_t timeout_ms);
+RT_HIP_API rt_hip_status rt_hip_join_frame_group(rt_hip_ctx* ctx, int rank, int world, const char* name, uint32_t timeout_ms);
 
 /* How the stripes of a multi-GPU frame reach the root: what a context was created with (and what a bench line should say). */
 enum
@@ -319,21 +330,21 @@ enum
 /* What member `member` of the context talks through, as RCCL itself reports it (rccl.h: ncclCommCount, ncclCommUserRank,
  * ncclCommCuDevice): the communicator's size, this member's rank in it, and the device the communicator lives on.  Contexts
  * without a communicator (one GPU, peer copies) report the context's own world / rank / device.  Any out pointer may be NULL. */
-rt_hip_status rt_hip_comm_info(const rt_hip_ctx* ctx, int member, int* out_ranks, int* out_rank, int* out_device, uint32_t* out_transport);
+RT_HIP_API rt_hip_status rt_hip_comm_info(const rt_hip_ctx* ctx, int member, int* out_ranks, int* out_rank, int* out_device, uint32_t* out_transport);
 
 /* number of members of a context (1 for rt_hip_create) and the device of member `rank` */
-rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count);
-rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device);
+RT_HIP_API rt_hip_status rt_hip_member_count(const rt_hip_ctx* ctx, int* out_count);
+RT_HIP_API rt_hip_status rt_hip_member_device(const rt_hip_ctx* ctx, int rank, int* out_device);
 /* counters of member `rank`'s share of the most recent rt_hip_render (rt_hip_stats_fetch on a multi context returns the
  * whole frame: counts summed, render_ms = the slowest member) */
-rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_stats);
+RT_HIP_API rt_hip_status rt_hip_member_stats(rt_hip_ctx* ctx, int rank, rt_hip_stats* out_stats);
 
 /* ---- partition helpers (pure host arithmetic; usable without a GPU) ------------------------------------------- */
 
 /* Rows of an H-row image owned by part->rank. */
-rt_hip_status rt_hip_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
+RT_HIP_API rt_hip_status rt_hip_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
 /* max over ranks of rt_hip_local_rows: the per-rank buffer height used for the equal-sized gather. */
-rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
+RT_HIP_API rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* part, uint32_t* out_rows);
 
 /*
  * What rt_hip_render does with the caller's columns before anything touches a GPU, on its own (pure host code; usable
@@ -342,14 +353,14 @@ rt_hip_status rt_hip_padded_local_rows(uint32_t height, const rt_hip_partition* 
  * caller's (rt has no scene version counter, src/main.cpp:233-311).  Reads exactly n_* rows of every column — never the
  * padding rows soagen keeps behind size() (vendor/soagen.hpp:3777,7075-7082).  out_fingerprint may be NULL.
  */
-rt_hip_status rt_hip_scene_check(const rt_hip_scene* scene, uint64_t* out_fingerprint);
+RT_HIP_API rt_hip_status rt_hip_scene_check(const rt_hip_scene* scene, uint64_t* out_fingerprint);
 
 /* ---- the hot path ----------------------------------------------------------------------------------------------- */
 
 /* Copy the scene columns to HBM (once per scene/camera change).  The reference has no scene version
  * counter (src/main.cpp:233-311), so rt_hip_render() calls this every frame; a caller that knows the
  * scene is unchanged keeps it resident and calls rt_hip_render_device() only. */
-rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene);
+RT_HIP_API rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene);
 
 /*
  * Render this rank's stripes of a width x height frame from the resident scene.
@@ -361,7 +372,7 @@ rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene* scene);
  *             src/random.cpp:12-13, and is not reproducible).
  *   stream    hipStream_t to launch on (NULL = the default stream).  Asynchronous: returns after enqueue.
  */
-rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
+RT_HIP_API rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 								   uint32_t width,
 								   uint32_t height,
 								   uint64_t seed,
@@ -373,7 +384,7 @@ rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,
 
 /* Rank 0, after the gather: de-interleave `world` compact per-rank buffers (each padded_local_rows x width,
  * concatenated in rank order) into the width x height frame.  Device to device, asynchronous on `stream`. */
-rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
+RT_HIP_API rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
 									 uint32_t width,
 									 uint32_t height,
 									 uint32_t world,
@@ -383,7 +394,7 @@ rt_hip_status rt_hip_assemble_device(rt_hip_ctx* ctx,
 									 void* stream);
 
 /* Synchronise with the last render on this context and read its counters. */
-rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats);
+RT_HIP_API rt_hip_status rt_hip_stats_fetch(rt_hip_ctx* ctx, rt_hip_stats* out_stats);
 
 /*
  * Where the time of the most recent rt_hip_render went (frames rendered with `stats` or RT_HIP_FLAG_STATS; otherwise the
@@ -401,7 +412,7 @@ typedef struct rt_hip_phases
 	uint32_t transport;	 /* RT_HIP_TRANSPORT_* that this frame took */
 	uint32_t scene_resident; /* 1: the columns' fingerprint matched, nothing was uploaded */
 } rt_hip_phases;
-rt_hip_status rt_hip_phases_fetch(rt_hip_ctx* ctx, rt_hip_phases* out_phases);
+RT_HIP_API rt_hip_status rt_hip_phases_fetch(rt_hip_ctx* ctx, rt_hip_phases* out_phases);
 
 /*
  * The drop-in for renderer_interface::render(const scene&, image_view&, muu::thread_pool&)
@@ -411,7 +422,7 @@ rt_hip_status rt_hip_phases_fetch(rt_hip_ctx* ctx, rt_hip_phases* out_phases);
  *   rgb_f32  optional HOST buffer of 3*width*height floats (pre-gamma mean), may be NULL.
  *   stats    optional, may be NULL.
  */
-rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
+RT_HIP_API rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 							const rt_hip_scene* scene,
 							uint32_t* pixels_rgba8888,
 							uint32_t width,
@@ -422,33 +433,13 @@ rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 							rt_hip_stats* stats);
 
 /* Drop the page-lock taken under RT_HIP_FLAG_PERSISTENT_FRAME (see there).  Waits for the context's stream first. */
-void rt_hip_forget_frame(rt_hip_ctx* ctx);
+RT_HIP_API void rt_hip_forget_frame(rt_hip_ctx* ctx);
 
-/* ---- known-answer entry points (device implementations of the path's leaf functions, for parity tests) -------- */
-
-/* out[i] = bits of the i-th draw: rt_hip random stream (seed, pixel, sample, draw k) for k in [0, n). */
-rt_hip_status rt_hip_kat_random(rt_hip_ctx* ctx, uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
-
-/* For n rays (origin/direction as 3 floats each, AoS) against the resident scene: closest-hit distance
- * (< 0 = miss), primitive kind (0 none, 1 sphere, 2 plane), primitive index, and hit normal (3 floats). */
-rt_hip_status rt_hip_kat_closest_hit(rt_hip_ctx* ctx,
-									 uint32_t n,
-									 const float* origins,
-									 const float* directions,
-									 float* out_distance,
-									 uint32_t* out_kind,
-									 uint32_t* out_index,
-									 float* out_normal);
-
-/* out_sqrt[i] = sqrtf(a[i]), out_div[i] = a[i] / b[i] as the device computes them (must be correctly rounded). */
-rt_hip_status rt_hip_kat_sqrt_div(rt_hip_ctx* ctx, uint32_t n, const float* a, const float* b, float* out_sqrt, float* out_div);
-
-/* Runs ALL 2^32 binary32 bit patterns through the kernels' shortened sqrt / reciprocal / reciprocal-sqrt sequences and
- * compares each result, bit for bit, with the compiler's general correctly rounded expansion (sqrt, reciprocal) and with
- * the arithmetic contract's definition of normalize()'s reciprocal square root evaluated through binary64.
- * out_mismatches[k] = number of differing inputs, out_first[k] = smallest differing input's bits (valid if count > 0),
- * k = 0 sqrt, 1 reciprocal, 2 reciprocal of sqrt.  All three counts must be 0. */
-rt_hip_status rt_hip_kat_exhaustive_math(rt_hip_ctx* ctx, uint64_t out_mismatches[3], uint32_t out_first[3]);
+/* Page-locks on CALLERS' memory that contexts of this process hold right now: 0 unless somebody rendered with
+ * RT_HIP_FLAG_PERSISTENT_FRAME (or as a rank of a frame group) and has neither moved on to another buffer nor called
+ * rt_hip_forget_frame / rt_hip_destroy since.  A diagnostic for integrators and for this repository's tests (which assert
+ * 0 after every GPU test): memory the module no longer knows about can never be written by it. */
+RT_HIP_API uint32_t rt_hip_live_frame_locks(void);
 
 #ifdef __cplusplus
 }

@@ -3,7 +3,7 @@
 Product code only.  The CPU oracle is test infrastructure and lives in ``oracle/`` (never imported from here).
 """
 from .capi import RtHipError, RtHipPartition, RtHipScene, RtHipStats  # noqa: F401
-from .renderer import HipRayTracer, device_count, local_rows, padded_local_rows, scene_check, unique_id  # noqa: F401
+from .renderer import HipRayTracer, device_count, live_frame_locks, local_rows, padded_local_rows, scene_check, unique_id  # noqa: F401
 from .scene import Scene, SceneError, scene_from_arrays  # noqa: F401
 
 __all__ = [
@@ -15,6 +15,7 @@ __all__ = [
     "Scene",
     "SceneError",
     "device_count",
+    "live_frame_locks",
     "local_rows",
     "padded_local_rows",
     "scene_check",

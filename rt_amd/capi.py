@@ -165,6 +165,12 @@ RT_HIP_SYMBOLS = [
         [C.c_void_p, C.POINTER(RtHipScene), C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.c_void_p, C.POINTER(RtHipStats)],
     ),
     ("rt_hip_forget_frame", None, [C.c_void_p]),
+    ("rt_hip_live_frame_locks", C.c_uint32, []),
+]
+
+# every symbol include/rt_hip_kat.h declares — librt_hip_kat.so, the TEST-ONLY companion library (known-answer entry points)
+RT_HIP_KAT_SYMBOLS = [
+    ("rt_hip_kat_last_error", C.c_char_p, []),
     ("rt_hip_kat_random", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]),
     ("rt_hip_kat_closest_hit", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     ("rt_hip_kat_sqrt_div", C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -196,10 +202,17 @@ def _bind(lib: C.CDLL, symbols) -> C.CDLL:
 
 _hip_lib = None
 _host_lib = None
+_kat_lib = None
 
 
 def hip_library_path() -> Path:
     return Path(os.environ.get("RT_HIP_LIBRARY", LIB_DIR / "librt_hip.so"))
+
+
+def kat_library_path() -> Path:
+    """librt_hip_kat.so lies next to the librt_hip.so in use (an experiment build carries the entry points itself)."""
+    hip = hip_library_path()
+    return hip if hip.name != "librt_hip.so" else hip.with_name("librt_hip_kat.so")
 
 
 def host_library_path() -> Path:
@@ -226,6 +239,23 @@ def hip_lib() -> C.CDLL:
         if got != RT_HIP_ABI_VERSION:
             raise RtHipError(5, f"{path} has ABI version {got}, bindings expect {RT_HIP_ABI_VERSION}")
     return _hip_lib
+
+
+def kat_lib() -> C.CDLL:
+    """The test-only library of known-answer entry points (include/rt_hip_kat.h).  Tests only."""
+    global _kat_lib
+    if _kat_lib is None:
+        hip_lib()  # first: librt_hip_kat.so depends on it (and torch's copy of the HIP runtime must come before both)
+        path = kat_library_path()
+        if not path.exists():
+            raise RtHipError(2, f"{path} not found: build it with `make` (or __graft_entry__.build())")
+        _kat_lib = _bind(C.CDLL(str(path)), RT_HIP_KAT_SYMBOLS)
+    return _kat_lib
+
+
+def check_kat(status: int) -> None:
+    if status != 0:
+        raise RtHipError(status, kat_lib().rt_hip_kat_last_error().decode(errors="replace"))
 
 
 def host_lib() -> C.CDLL:

@@ -1,0 +1,290 @@
+// rt_amd/csrc/delivery.cpp — see delivery.hpp.
+#include "delivery.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+
+#if (defined(__x86_64__) || defined(_M_X64)) && !defined(RT_HIP_CARRIER_PORTABLE) // (the portable path: other hosts, and the ThreadSanitizer build of the test)
+#include <emmintrin.h>
+#define RT_HIP_CARRIER_SSE2 1
+#endif
+
+namespace rt_hip
+{
+	namespace
+	{
+		constexpr size_t line_bytes = 64;			  // what is copied, and checked for pending pixels, at a time
+		constexpr size_t pixel_band_bytes = 64u << 10; // a band of a frame in flight: 8.5 rows of a 1920-pixel frame
+		constexpr size_t copy_band_bytes = 256u << 10;
+		constexpr size_t small_frame_bytes = 128u << 10; // frames up to this size are not worth waking anybody for
+		constexpr auto stay_hot = std::chrono::microseconds(150); // a helper keeps looking for the next frame this long before it sleeps
+
+		inline void relax()
+		{
+#ifdef RT_HIP_CARRIER_SSE2
+			_mm_pause();
+#endif
+			asm volatile("" ::: "memory"); // whatever is polled is loaded again
+		}
+
+		// the 64-byte line at `from` if all of its sixteen pixels are there: copied to `to`, zeros put back; else nothing
+		inline bool take_line(unsigned char* from, unsigned char* to)
+		{
+#ifdef RT_HIP_CARRIER_SSE2
+			const __m128i zero = _mm_setzero_si128();
+			const __m128i a = _mm_load_si128(reinterpret_cast<const __m128i*>(from));
+			const __m128i b = _mm_load_si128(reinterpret_cast<const __m128i*>(from + 16));
+			const __m128i c = _mm_load_si128(reinterpret_cast<const __m128i*>(from + 32));
+			const __m128i d = _mm_load_si128(reinterpret_cast<const __m128i*>(from + 48));
+			const __m128i pending = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi32(a, zero), _mm_cmpeq_epi32(b, zero)), _mm_or_si128(_mm_cmpeq_epi32(c, zero), _mm_cmpeq_epi32(d, zero)));
+			if (_mm_movemask_epi8(pending) != 0)
+				return false;
+			_mm_storeu_si128(reinterpret_cast<__m128i*>(to), a);
+			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 16), b);
+			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 32), c);
+			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 48), d);
+			_mm_store_si128(reinterpret_cast<__m128i*>(from), zero);
+			_mm_store_si128(reinterpret_cast<__m128i*>(from + 16), zero);
+			_mm_store_si128(reinterpret_cast<__m128i*>(from + 32), zero);
+			_mm_store_si128(reinterpret_cast<__m128i*>(from + 48), zero);
+			return true;
+#else
+			uint32_t words[line_bytes / 4];
+			for (size_t k = 0; k < line_bytes / 4; k++)
+				words[k] = __atomic_load_n(reinterpret_cast<const uint32_t*>(from) + k, __ATOMIC_RELAXED);
+			for (const uint32_t w : words)
+				if (!w)
+					return false;
+			std::memcpy(to, words, line_bytes);
+			for (size_t k = 0; k < line_bytes / 4; k++)
+				__atomic_store_n(reinterpret_cast<uint32_t*>(from) + k, 0u, __ATOMIC_RELAXED);
+			return true;
+#endif
+		}
+
+		// whole words of [from, from + bytes) as they are now: a word that is still 0 was never stored and leaves the caller's
+		// word alone (the reference's caller has pre-cleared its frame, src/main.cpp:318)
+		inline void take_words(unsigned char* from, unsigned char* to, size_t bytes)
+		{
+			for (size_t at = 0; at + 4 <= bytes; at += 4)
+			{
+				const uint32_t w = __atomic_load_n(reinterpret_cast<const uint32_t*>(from + at), __ATOMIC_RELAXED);
+				if (w)
+				{
+					std::memcpy(to + at, &w, 4);
+					__atomic_store_n(reinterpret_cast<uint32_t*>(from + at), 0u, __ATOMIC_RELAXED);
+				}
+			}
+		}
+
+		inline bool all_there(const unsigned char* from, size_t bytes)
+		{
+			for (size_t at = 0; at + 4 <= bytes; at += 4)
+				if (!__atomic_load_n(reinterpret_cast<const uint32_t*>(from + at), __ATOMIC_RELAXED))
+					return false;
+			return true;
+		}
+	}
+
+	pixel_carrier::pixel_carrier(unsigned helpers)
+	{
+		threads_.reserve(helpers);
+		for (unsigned i = 0; i < helpers; i++)
+			threads_.emplace_back([this] { helper_main(); });
+	}
+
+	pixel_carrier::~pixel_carrier()
+	{
+		if (in_flight_)
+			abandon();
+		{
+			const std::lock_guard<std::mutex> lock(mutex_);
+			quit_ = true;
+		}
+		quit_hint_.store(true, std::memory_order_release);
+		wake_.notify_all();
+		for (std::thread& t : threads_)
+			t.join();
+	}
+
+	void pixel_carrier::helper_main()
+	{
+		uint64_t seen = 0;
+		for (;;)
+		{
+			// a renderer is asked for frame after frame: stay awake for a moment after each
+			bool fresh = false;
+			const auto until = std::chrono::steady_clock::now() + stay_hot;
+			for (unsigned spins = 0;; spins++)
+			{
+				if (posted_.load(std::memory_order_acquire) != seen)
+				{
+					fresh = true;
+					break;
+				}
+				if (quit_hint_.load(std::memory_order_acquire))
+					return;
+				if ((spins & 63u) == 63u && std::chrono::steady_clock::now() >= until)
+					break;
+				relax();
+			}
+			if (!fresh)
+			{
+				sleepers_.fetch_add(1, std::memory_order_seq_cst);
+				{
+					std::unique_lock<std::mutex> lock(mutex_);
+					wake_.wait(lock, [&] { return quit_ || posted_.load(std::memory_order_seq_cst) != seen; });
+					if (quit_)
+					{
+						sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+						return;
+					}
+				}
+				sleepers_.fetch_sub(1, std::memory_order_seq_cst);
+			}
+			seen = posted_.load(std::memory_order_acquire);
+			// enter only an OPEN job (its fields are valid then): this thread announces itself first and looks second, the
+			// caller's thread closes first and waits for the announced second — one of the two always sees the other
+			inside_.fetch_add(1, std::memory_order_seq_cst);
+			if (open_.load(std::memory_order_seq_cst))
+				work();
+			inside_.fetch_sub(1, std::memory_order_seq_cst);
+		}
+	}
+
+	void pixel_carrier::post()
+	{
+		open_.store(true, std::memory_order_seq_cst);
+		posted_.fetch_add(1, std::memory_order_seq_cst);
+		if (sleepers_.load(std::memory_order_seq_cst) != 0)
+		{
+			{
+				const std::lock_guard<std::mutex> lock(mutex_); // (a helper between its predicate and its wait holds this lock)
+			}
+			wake_.notify_all();
+		}
+	}
+
+	void pixel_carrier::close()
+	{
+		open_.store(false, std::memory_order_seq_cst);
+		while (inside_.load(std::memory_order_seq_cst) != 0)
+			relax();
+	}
+
+	void pixel_carrier::work()
+	{
+		for (;;)
+		{
+			const size_t claimed = next_band_.fetch_add(1, std::memory_order_relaxed);
+			if (claimed >= bands_)
+				return;
+			if (kind_ == copy_bytes)
+			{
+				const size_t at = claimed * band_bytes_;
+				std::memcpy(to_ + at, from_ + at, std::min(band_bytes_, bytes_ - at));
+			}
+			else
+				carry_band(bands_ - 1u - claimed); // the launches hand their tiles out bottom row first
+			bands_done_.fetch_add(1, std::memory_order_release);
+		}
+	}
+
+	void pixel_carrier::carry_band(size_t band)
+	{
+		const size_t begin = band * band_bytes_;
+		const size_t end = std::min(bytes_, begin + band_bytes_);
+		size_t at = begin;
+		while (at < end)
+		{
+			const size_t n = std::min(line_bytes, end - at);
+			for (;;)
+			{
+				if (n == line_bytes ? take_line(from_ + at, to_ + at) : all_there(from_ + at, n))
+				{
+					if (n != line_bytes)
+						take_words(from_ + at, to_ + at, n);
+					break;
+				}
+				const uint32_t state = state_.load(std::memory_order_acquire);
+				if (state == abandoned)
+					return;
+				if (state == drained)
+				{
+					take_words(from_ + at, to_ + at, n); // (loaded after the acquire: what the device stored, all of it)
+					break;
+				}
+				relax();
+			}
+			at += n;
+		}
+	}
+
+	void pixel_carrier::begin(uint32_t* from, uint32_t* to, size_t words)
+	{
+		if (in_flight_)
+			abandon();
+		close();
+		kind_ = carry_pixels;
+		from_ = reinterpret_cast<unsigned char*>(from);
+		to_ = reinterpret_cast<unsigned char*>(to);
+		bytes_ = words * sizeof(uint32_t);
+		band_bytes_ = pixel_band_bytes;
+		bands_ = (bytes_ + band_bytes_ - 1u) / band_bytes_;
+		next_band_.store(0, std::memory_order_relaxed);
+		bands_done_.store(0, std::memory_order_relaxed);
+		state_.store(storing, std::memory_order_relaxed);
+		early_bands_ = 0;
+		in_flight_ = true;
+		if (!threads_.empty() && bytes_ > small_frame_bytes)
+			post();
+	}
+
+	void pixel_carrier::finish()
+	{
+		if (!in_flight_)
+			return;
+		early_bands_ = bands_done_.load(std::memory_order_acquire);
+		state_.store(drained, std::memory_order_release);
+		work();
+		while (bands_done_.load(std::memory_order_acquire) != bands_)
+			relax();
+		close();
+		in_flight_ = false;
+	}
+
+	void pixel_carrier::abandon()
+	{
+		if (!in_flight_)
+			return;
+		state_.store(abandoned, std::memory_order_release);
+		close();
+		in_flight_ = false;
+	}
+
+	void pixel_carrier::copy(void* to, const void* from, size_t bytes)
+	{
+		if (in_flight_ || !bytes)
+			return;
+		if (threads_.empty() || bytes <= copy_band_bytes)
+		{
+			std::memcpy(to, from, bytes);
+			return;
+		}
+		close();
+		kind_ = copy_bytes;
+		from_ = static_cast<unsigned char*>(const_cast<void*>(from));
+		to_ = static_cast<unsigned char*>(to);
+		bytes_ = bytes;
+		band_bytes_ = copy_band_bytes;
+		bands_ = (bytes_ + band_bytes_ - 1u) / band_bytes_;
+		next_band_.store(0, std::memory_order_relaxed);
+		bands_done_.store(0, std::memory_order_relaxed);
+		post();
+		work();
+		while (bands_done_.load(std::memory_order_acquire) != bands_)
+			relax();
+		close();
+	}
+}

@@ -39,6 +39,7 @@
 // hardware approximations), where it provides launch_render_fast() and nothing else.
 #include "kernels.hpp"
 #include "contract.hpp"
+#include "scan.hpp"
 
 #ifdef RT_HIP_FAST_BUILD
 #define render_queue render_queue_fast
@@ -79,111 +80,6 @@ namespace rt_hip
 {
 	namespace
 	{
-		constexpr uint32_t block_threads = 256;
-
-		// best candidate of one linear scan (test_planes / test_spheres, mg_ray_tracer.cpp:36-87)
-		struct candidate
-		{
-			float t;
-			uint32_t index;
-			bool have;
-		};
-
-		// One sphere of test_spheres (:70-79) for all lanes at once, in two halves: the part every lane needs
-		// (discriminant) and the part only a possible hit needs (square root, distance, comparison with the best so far).
-		struct sphere_probe
-		{
-			float a, e2, disc;
-			bool pos; // hits_sphere did not return at `if (disc < 0)`
-		};
-
-		__device__ __forceinline__ sphere_probe probe_sphere(vec3 o, vec3 d, float4 s) // s = (center, radius^2), wave-uniform
-		{
-			const vec3 e = { s.x - o.x, s.y - o.y, s.z - o.z };
-			sphere_probe p;
-			p.a = dot(e, d);
-			p.e2 = dot(e, e);
-			p.disc = s.w - fma(-p.a, p.a, p.e2);
-			p.pos = !(p.disc < 0.0f);
-			return p;
-		}
-
-		// `lanes` = ballot of p.pos
-		__device__ __forceinline__ void finish_sphere(candidate& best, const sphere_probe& p, float r2, uint32_t index, unsigned long long lanes)
-		{
-			if (lanes != 0) // no lane can hit: skip the square root for the whole wave
-			{
-				const float f = sqrt_rn_where(p.disc, p.pos); // lanes with disc < 0 never use f
-				const float t = (p.e2 < r2) ? p.a + f : p.a - f;
-				// hits() holds a value <=> pos && !(t < 0); the scan then drops t < min_hit_dist (which covers
-				// t < 0) and anything not closer than the best so far: `hit_index && hit_dist <= *hit` (:74)
-				const bool accept = p.pos && !(t < min_hit_dist) && !(best.have && best.t <= t);
-				best.t = accept ? t : best.t;
-				best.index = accept ? index : best.index;
-				best.have = best.have || accept;
-			}
-		}
-
-		__device__ __forceinline__ void test_sphere(candidate& best, vec3 o, vec3 d, float4 s, uint32_t index)
-		{
-			const sphere_probe p = probe_sphere(o, d, s);
-			finish_sphere(best, p, s.w, index, __builtin_amdgcn_ballot_w64(p.pos));
-		}
-
-		// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
-		__device__ __forceinline__ void test_plane(candidate& best, vec3 o, vec3 d, float4 pl, uint32_t index)
-		{
-			const vec3 n = { pl.x, pl.y, pl.z };
-			const float den = dot(n, d);
-			const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
-			if (__builtin_amdgcn_ballot_w64(crosses) != 0)
-			{
-				const float num = dot(n, o) + pl.w;
-				const float t = divide(-num, crosses ? den : 1.0f);
-				const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
-				best.t = accept ? t : best.t;
-				best.index = accept ? index : best.index;
-				best.have = best.have || accept;
-			}
-		}
-
-		// scan `count` primitives held in LDS (wave-uniform addresses: broadcast reads).  Spheres go four at a time:
-		// four independent discriminants (instruction-level parallelism, LDS reads issued together), ONE ballot for
-		// the group; the square-root halves run, in index order, only if some lane may hit one of the four.
-		template <bool SPHERES>
-		__device__ __forceinline__ void scan_lds(candidate& best, vec3 o, vec3 d, const float4* lds, uint32_t count, uint32_t first_index)
-		{
-			uint32_t i = 0;
-			if (SPHERES)
-			{
-				for (; i + 4 <= count; i += 4)
-				{
-					const float4 s0 = lds[i], s1 = lds[i + 1], s2 = lds[i + 2], s3 = lds[i + 3];
-					const sphere_probe p0 = probe_sphere(o, d, s0);
-					const sphere_probe p1 = probe_sphere(o, d, s1);
-					const sphere_probe p2 = probe_sphere(o, d, s2);
-					const sphere_probe p3 = probe_sphere(o, d, s3);
-					// the four comparison masks are combined on the scalar unit
-					const unsigned long long m0 = __builtin_amdgcn_ballot_w64(p0.pos), m1 = __builtin_amdgcn_ballot_w64(p1.pos);
-					const unsigned long long m2 = __builtin_amdgcn_ballot_w64(p2.pos), m3 = __builtin_amdgcn_ballot_w64(p3.pos);
-					if ((m0 | m1 | m2 | m3) != 0)
-					{
-						finish_sphere(best, p0, s0.w, first_index + i, m0);
-						finish_sphere(best, p1, s1.w, first_index + i + 1, m1);
-						finish_sphere(best, p2, s2.w, first_index + i + 2, m2);
-						finish_sphere(best, p3, s3.w, first_index + i + 3, m3);
-					}
-				}
-			}
-			for (; i < count; i++)
-			{
-				if (SPHERES)
-					test_sphere(best, o, d, lds[i], first_index + i);
-				else
-					test_plane(best, o, d, lds[i], first_index + i);
-			}
-		}
-
 		// The streamed kernel's sphere scan: the (center, radius^2) table is read from HBM/L2 with wave-uniform scalar loads,
 		// four spheres = 64 bytes = one s_load_dwordx16.  Every wave of a CU walks the 1.6 MB table at its own position, so
 		// the 16 KB scalar cache holds next to nothing of it (SQC_DCACHE: 29 % hits at 100 000 spheres,
@@ -297,39 +193,6 @@ namespace rt_hip
 			return true;
 		}
 
-		// cooperative copy of `count` primitives starting at `first` from the SoA columns into float4 LDS slots;
-		// lane i of the workgroup reads element first+i of each column (coalesced), radius is squared on the way in
-		__device__ __forceinline__ void stage_spheres(float4* lds, const device_scene& s, uint32_t first, uint32_t count)
-		{
-			for (uint32_t i = threadIdx.x; i < count; i += block_threads)
-			{
-				const float r = s.sphere_r[first + i];
-				lds[i] = make_float4(s.sphere_cx[first + i], s.sphere_cy[first + i], s.sphere_cz[first + i], r * r);
-			}
-		}
-
-		__device__ __forceinline__ void stage_planes(float4* lds, const device_scene& s, uint32_t first, uint32_t count)
-		{
-			for (uint32_t i = threadIdx.x; i < count; i += block_threads)
-				lds[i] = make_float4(s.plane_nx[first + i], s.plane_ny[first + i], s.plane_nz[first + i], s.plane_d[first + i]);
-		}
-
-		// select(test_spheres, test_planes), then select(test_boxes, ...) which never changes anything —
-		// mg_ray_tracer.cpp:96-102,160-162.  `operator bool` of hit_result is `distance >= 0` (:29-32), which also
-		// rejects a NaN distance.  Returns 0 = miss, 1 = sphere, 2 = plane.
-		__device__ __forceinline__ uint32_t select_hit(const candidate& spheres, const candidate& planes, float& distance, uint32_t& index)
-		{
-			const float sphere_distance = spheres.have ? spheres.t : -1.0f;
-			const float plane_distance = planes.have ? planes.t : -1.0f;
-			const bool a = sphere_distance >= 0.0f;
-			const bool b = plane_distance >= 0.0f;
-			const bool use_sphere = a && (!b || sphere_distance <= plane_distance);
-			const bool use_plane = !use_sphere && b;
-			distance = use_sphere ? sphere_distance : (use_plane ? plane_distance : -1.0f);
-			index = use_sphere ? spheres.index : planes.index;
-			return use_sphere ? 1u : (use_plane ? 2u : 0u);
-		}
-
 		// everything a lane carries between loop trips
 		struct lane_state
 		{
@@ -381,25 +244,6 @@ namespace rt_hip
 		{
 			if ((threadIdx.x & 63u) == 0 && segments)
 				atomicAdd(&counters->segments[(blockIdx.x + blockIdx.y * 7u + (threadIdx.x >> 6)) % device_counters::segment_counters], segments);
-		}
-
-		// lookups of the winning primitive from the global per-primitive tables (one indexed read each)
-		template <bool SM>
-		__device__ __forceinline__ void
-		fetch_hit(const device_scene& s, vec3 o, vec3 d, uint32_t kind, float distance, uint32_t index, vec3& normal, float4& shading, uint32_t& scatter)
-		{
-			scatter = scatter_lambert;
-			if (kind) // normal and shading are meaningful only for a hit
-			{
-				const uint32_t primitive = kind == 1u ? index : s.n_spheres + index;
-				const float4 g = s.primitive_geometry[primitive];
-				shading = SM ? s.primitive_shading_sm[primitive] : s.primitive_shading[primitive];
-				scatter = SM ? s.primitive_scatter_sm[primitive] : s.primitive_scatter[primitive];
-				if (kind == 1u)
-					normal = normalize(ray_at(o, d, distance) - vec3{ g.x, g.y, g.z }); // (:85)
-				else
-					normal = { g.x, g.y, g.z }; // the plane's normal, not flipped toward the ray (:58)
-			}
 		}
 
 		// ---- small / resident kernel: a wave works through a queue of (pixel, sample chunk) items -----------------------
@@ -1371,125 +1215,6 @@ namespace rt_hip
 				frame[static_cast<size_t>(y) * width + x] = word;
 		}
 
-		// ---- known-answer kernels -----------------------------------------------------------------------------------
-		__global__ void kat_random(frame_keys frame, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
-		{
-			if (blockIdx.x || threadIdx.x)
-				return;
-			stream_keys keys;
-			keys.function_key = pixel_function_key(frame.a, pixel);
-			keys.stride = pixel_stride(frame.b, keys.function_key);
-			uint32_t counter = sample_counter(keys.stride, sample);
-			for (uint32_t i = 0; i < n; i++)
-				out[i] = next_random(counter, keys);
-		}
-
-		__global__ __launch_bounds__(block_threads) void kat_closest_hit(const device_scene s,
-																		 uint32_t n,
-																		 const float* __restrict__ origins,
-																		 const float* __restrict__ directions,
-																		 float* __restrict__ out_distance,
-																		 uint32_t* __restrict__ out_kind,
-																		 uint32_t* __restrict__ out_index,
-																		 float* __restrict__ out_normal)
-		{
-			__shared__ float4 tile[tile_primitives];
-			const uint32_t i = blockIdx.x * block_threads + threadIdx.x;
-			const bool alive = i < n;
-			vec3 o = { 0, 0, 0 }, d = { 0, 0, 1 };
-			if (alive)
-			{
-				o = { origins[i * 3], origins[i * 3 + 1], origins[i * 3 + 2] };
-				d = { directions[i * 3], directions[i * 3 + 1], directions[i * 3 + 2] };
-			}
-			candidate planes = { 0.0f, 0u, false };
-			candidate spheres = { 0.0f, 0u, false };
-			for (uint32_t first = 0; first < s.n_planes; first += tile_primitives)
-			{
-				const uint32_t count = min(tile_primitives, s.n_planes - first);
-				__syncthreads();
-				stage_planes(tile, s, first, count);
-				__syncthreads();
-				if (alive)
-					scan_lds<false>(planes, o, d, tile, count, first);
-			}
-			for (uint32_t first = 0; first < s.n_spheres; first += tile_primitives)
-			{
-				const uint32_t count = min(tile_primitives, s.n_spheres - first);
-				__syncthreads();
-				stage_spheres(tile, s, first, count);
-				__syncthreads();
-				if (alive)
-					scan_lds<true>(spheres, o, d, tile, count, first);
-			}
-			if (alive)
-			{
-				float distance;
-				uint32_t index;
-				const uint32_t kind = select_hit(spheres, planes, distance, index);
-				vec3 normal;
-				float4 shading;
-				uint32_t scatter;
-				fetch_hit<false>(s, o, d, kind, distance, index, normal, shading, scatter);
-				if (!kind)
-					normal = { 0.0f, 0.0f, 0.0f }; // hit_result{ -1 } of the reference: no normal
-				out_distance[i] = distance;
-				out_kind[i] = kind;
-				out_index[i] = kind ? index : 0u;
-				out_normal[i * 3 + 0] = normal.x;
-				out_normal[i * 3 + 1] = normal.y;
-				out_normal[i * 3 + 2] = normal.z;
-			}
-		}
-
-		__global__ void kat_sqrt_div(uint32_t n, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out_sqrt, float* __restrict__ out_div)
-		{
-			const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-			if (i < n)
-			{
-				out_sqrt[i] = __builtin_sqrtf(a[i]);
-				out_div[i] = a[i] / b[i];
-			}
-		}
-
-		// every one of the 2^32 binary32 bit patterns through sqrt_rn / rcp_rn / inv_sqrt_rn against hipcc's general
-		// correctly rounded expansions (inv_sqrt_rn: against the contract's definition, evaluated through binary64);
-		// result[2k] = mismatches, result[2k+1] = smallest mismatching input + 1
-		__device__ __forceinline__ bool same_float(float a, float b)
-		{
-			return __float_as_uint(a) == __float_as_uint(b) || (a != a && b != b);
-		}
-
-		__global__ __launch_bounds__(block_threads) void kat_exhaustive_math(unsigned long long* __restrict__ result)
-		{
-			const uint32_t tid = blockIdx.x * block_threads + threadIdx.x; // 2^22 threads x 2^10 patterns each
-			uint32_t bad[3] = { 0, 0, 0 };
-			unsigned long long first[3] = { ~0ull, ~0ull, ~0ull };
-			for (uint32_t k = 0; k < 1024u; k++)
-			{
-				const uint32_t bits = (k << 22) | tid;
-				const float x = __uint_as_float(bits);
-				const bool ok[3] = { same_float(sqrt_rn(x), __builtin_sqrtf(x)),
-									 same_float(rcp_rn(x), 1.0f / x),
-									 same_float(inv_sqrt_rn(x), inv_sqrt_definition(x)) };
-#pragma unroll
-				for (int f = 0; f < 3; f++)
-					if (!ok[f])
-					{
-						bad[f]++;
-						if (static_cast<unsigned long long>(bits) + 1ull < first[f])
-							first[f] = static_cast<unsigned long long>(bits) + 1ull;
-					}
-			}
-#pragma unroll
-			for (int f = 0; f < 3; f++)
-				if (bad[f])
-				{
-					atomicAdd(&result[2 * f], static_cast<unsigned long long>(bad[f]));
-					atomicMin(&result[2 * f + 1], first[f]);
-				}
-		}
-
 #endif // !RT_HIP_FAST_BUILD
 
 		template <int NS, bool SM>
@@ -1834,34 +1559,5 @@ namespace rt_hip
 			hipLaunchKernelGGL(assemble_stripes<false>, grid, dim3(block_threads), 0, stream, width, height, world, stripe_rows, padded_local_rows, first_rank, d_gathered, d_frame);
 	}
 
-	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream)
-	{
-		hipLaunchKernelGGL(kat_random, dim3(1), dim3(64), 0, stream, frame_keys{ frame_key_a, frame_key_b }, pixel, sample, n, d_out);
-	}
-
-	void launch_kat_closest_hit(const device_scene& scene,
-								uint32_t n,
-								const float* d_origins,
-								const float* d_directions,
-								float* d_distance,
-								uint32_t* d_kind,
-								uint32_t* d_index,
-								float* d_normal,
-								hipStream_t stream)
-	{
-		const dim3 grid((n + block_threads - 1) / block_threads);
-		hipLaunchKernelGGL(kat_closest_hit, grid, dim3(block_threads), 0, stream, scene, n, d_origins, d_directions, d_distance, d_kind, d_index, d_normal);
-	}
-
-	void launch_kat_sqrt_div(uint32_t n, const float* d_a, const float* d_b, float* d_sqrt, float* d_div, hipStream_t stream)
-	{
-		const dim3 grid((n + block_threads - 1) / block_threads);
-		hipLaunchKernelGGL(kat_sqrt_div, grid, dim3(block_threads), 0, stream, n, d_a, d_b, d_sqrt, d_div);
-	}
-
-	void launch_kat_exhaustive_math(unsigned long long* d_result, hipStream_t stream)
-	{
-		hipLaunchKernelGGL(kat_exhaustive_math, dim3((1u << 22) / block_threads), dim3(block_threads), 0, stream, d_result);
-	}
 #endif // !RT_HIP_FAST_BUILD
 }

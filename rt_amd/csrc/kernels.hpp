@@ -231,18 +231,4 @@ namespace rt_hip
 						 uint32_t first_rank,		// rows of ranks below this one are left alone (already in the frame)
 						 bool frame_is_host_memory, // the caller's page-locked back buffer: system-scope stores
 						 hipStream_t stream);
-
-	void launch_kat_random(uint32_t frame_key_a, uint32_t frame_key_b, uint32_t pixel, uint32_t sample, uint32_t n, float* d_out, hipStream_t stream);
-	void launch_kat_closest_hit(const device_scene& scene,
-								uint32_t n,
-								const float* d_origins,
-								const float* d_directions,
-								float* d_distance,
-								uint32_t* d_kind,
-								uint32_t* d_index,
-								float* d_normal,
-								hipStream_t stream);
-	void launch_kat_sqrt_div(uint32_t n, const float* d_a, const float* d_b, float* d_sqrt, float* d_div, hipStream_t stream);
-	// d_result: 3 x { mismatch count (u64), first mismatching input bits (u64) } for sqrt_rn, rcp_rn, inv_sqrt_rn
-	void launch_kat_exhaustive_math(unsigned long long* d_result, hipStream_t stream);
 }

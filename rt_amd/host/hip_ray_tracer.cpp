@@ -85,22 +85,26 @@ namespace
 				p = (*end == ',') ? end + 1 : end;
 			}
 		}
-		// RT_HIP_FRAME=direct: no gather — every GPU stores its pixels straight into the (page-locked) back buffer
+		// RT_HIP_FRAME=direct (or locked+direct): no gather — every GPU stores its pixels straight into the frame (the module's
+		// own page-locked one by default; rt's own back buffer with "locked")
 		const char* frame = std::getenv("RT_HIP_FRAME");
-		const uint32_t flags = (frame && std::strcmp(frame, "direct") == 0) ? static_cast<uint32_t>(RT_HIP_MULTI_DIRECT_FRAME) : static_cast<uint32_t>(RT_HIP_MULTI_NONE);
+		const uint32_t flags = (frame && std::strstr(frame, "direct")) ? static_cast<uint32_t>(RT_HIP_MULTI_DIRECT_FRAME) : static_cast<uint32_t>(RT_HIP_MULTI_NONE);
 		return rt_hip_create_multi(ctx, devices, n, flags); // n == 0 fails there with a message
 	}
 
-	// RT_HIP_FLAG_PERSISTENT_FRAME: rt keeps one image per window size (src/window.cpp:61-64), so the module may page-lock
-	// it once and render straight into it.  RT_HIP_FRAME=copy withholds the flag (the frame then goes through HBM and one
-	// copy): for a build of rt that may free an image and get the same address and size back between two frames without
-	// calling rt_hip_forget_frame (INTEGRATION.md §3 "The back buffer").
+	// The default passes NO frame flag: the module renders into a page-locked frame of its own and its host threads carry the
+	// pixels into rt's image while the frame is still being traced.  rt's image stays plain memory to the module — rt
+	// re-creates its images on resize, also while another renderer is the active one (src/window.cpp:198-203,213), and a
+	// renderer's render() is noexcept / void with nowhere to report a fault (src/renderer.hpp:11).
+	// RT_HIP_FRAME=locked opts in to RT_HIP_FLAG_PERSISTENT_FRAME (rt's image itself is page-locked and mapped; the kernels
+	// store straight into it, a few tens of microseconds less per frame): only for a build of rt that calls
+	// rt_hip_forget_frame wherever it re-creates its images (INTEGRATION.md §3 "The back buffer").
 	uint32_t frame_flags()
 	{
 		static const uint32_t flags = []
 		{
 			const char* frame = std::getenv("RT_HIP_FRAME");
-			return (frame && std::strcmp(frame, "copy") == 0) ? static_cast<uint32_t>(RT_HIP_FLAG_NONE) : static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME);
+			return (frame && std::strstr(frame, "locked")) ? static_cast<uint32_t>(RT_HIP_FLAG_PERSISTENT_FRAME) : static_cast<uint32_t>(RT_HIP_FLAG_NONE);
 		}();
 		return flags;
 	}

@@ -48,6 +48,11 @@ def unique_id() -> bytes:
     return bytes(buf.raw)
 
 
+def live_frame_locks() -> int:
+    """rt_hip_live_frame_locks: page-locks on callers' memory that contexts of this process hold right now."""
+    return int(capi.hip_lib().rt_hip_live_frame_locks())
+
+
 def device_count() -> int:
     n = C.c_int()
     check(capi.hip_lib().rt_hip_device_count(C.byref(n)))
@@ -206,10 +211,10 @@ class HipRayTracer:
         check(self._lib.rt_hip_member_stats(self._ctx, rank, C.byref(stats)))
         return stats.as_dict()
 
-    # ---- known-answer entry points ------------------------------------------------------------------------
+    # ---- known-answer entry points (librt_hip_kat.so: test-only, include/rt_hip_kat.h) ---------------------
     def kat_random(self, seed: int, pixel: int, sample: int, n: int) -> np.ndarray:
         out = np.empty(n, dtype=np.float32)
-        check(self._lib.rt_hip_kat_random(self._ctx, seed, pixel, sample, n, out.ctypes.data))
+        capi.check_kat(capi.kat_lib().rt_hip_kat_random(self._ctx, seed, pixel, sample, n, out.ctypes.data))
         return out
 
     def kat_closest_hit(self, origins: np.ndarray, directions: np.ndarray):
@@ -220,7 +225,7 @@ class HipRayTracer:
         kind = np.empty(n, dtype=np.uint32)
         index = np.empty(n, dtype=np.uint32)
         normal = np.empty((n, 3), dtype=np.float32)
-        check(self._lib.rt_hip_kat_closest_hit(self._ctx, n, o.ctypes.data, d.ctypes.data, dist.ctypes.data, kind.ctypes.data, index.ctypes.data, normal.ctypes.data))
+        capi.check_kat(capi.kat_lib().rt_hip_kat_closest_hit(self._ctx, n, o.ctypes.data, d.ctypes.data, dist.ctypes.data, kind.ctypes.data, index.ctypes.data, normal.ctypes.data))
         return dist, kind, index, normal
 
     def kat_sqrt_div(self, a: np.ndarray, b: np.ndarray):
@@ -228,7 +233,7 @@ class HipRayTracer:
         b = np.ascontiguousarray(b, dtype=np.float32)
         s = np.empty_like(a)
         q = np.empty_like(a)
-        check(self._lib.rt_hip_kat_sqrt_div(self._ctx, a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data))
+        capi.check_kat(capi.kat_lib().rt_hip_kat_sqrt_div(self._ctx, a.size, a.ctypes.data, b.ctypes.data, s.ctypes.data, q.ctypes.data))
         return s, q
 
     def kat_exhaustive_math(self):
@@ -236,5 +241,5 @@ class HipRayTracer:
         compiler's correctly rounded expansions: ([mismatch counts], [first mismatching input bits])."""
         counts = (C.c_uint64 * 3)()
         first = (C.c_uint32 * 3)()
-        check(self._lib.rt_hip_kat_exhaustive_math(self._ctx, C.byref(counts), C.byref(first)))
+        capi.check_kat(capi.kat_lib().rt_hip_kat_exhaustive_math(self._ctx, C.byref(counts), C.byref(first)))
         return list(counts), list(first)

@@ -26,6 +26,9 @@ class Scene:
         if not handle:
             raise SceneError(capi.host_lib().rt_host_last_error().decode(errors="replace"))
         self._handle = C.c_void_p(handle)
+        # bound now: at interpreter shutdown the module globals that capi.host_lib() needs may already be gone (round 3 saw
+        # "TypeError: 'NoneType' object is not callable" from __del__ at exit)
+        self._free = capi.host_lib().rt_host_scene_free
 
     # ---- constructors -------------------------------------------------------------------------------------
     @classmethod
@@ -51,8 +54,9 @@ class Scene:
 
     def __del__(self):
         handle, self._handle = getattr(self, "_handle", None), None
-        if handle and capi is not None and getattr(capi, "host_lib", None) is not None:  # (None during interpreter shutdown)
-            capi.host_lib().rt_host_scene_free(handle)
+        free = getattr(self, "_free", None)
+        if handle and free is not None:
+            free(handle)
 
     # ---- mutation -------------------------------------------------------------------------------------------
     def set_sampling(self, samples_per_pixel: int = 0, max_bounces: int = 0) -> "Scene":

@@ -26,6 +26,19 @@ def _built():
         __graft_entry__.build()
 
 
+@pytest.fixture(autouse=True)
+def _no_page_lock_outlives_a_gpu_test(request):
+    """memory the module no longer knows about can never be written by it.  The module's default path keeps
+    nothing of the caller's memory at all; the opt-in page-lock (RT_HIP_FLAG_PERSISTENT_FRAME, frame groups) must be gone —
+    forgotten, replaced or destroyed with its context — by the time the test that took it is over, or the numpy arrays the
+    next tests allocate could come to lie under a live lock."""
+    yield
+    if request.node.get_closest_marker("gpu") is not None:
+        import rt_amd
+
+        assert rt_amd.live_frame_locks() == 0, "a page-lock on a test's buffer outlived the test (rt_hip_forget_frame missing?)"
+
+
 @pytest.fixture(scope="session")
 def tracer():
     """One rt_hip context on GPU 0 for the whole session.  No skip: without a gfx950 device this FAILS."""

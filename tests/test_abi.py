@@ -16,6 +16,14 @@ def declared_functions(header_text: str):
     return sorted(set(re.findall(r"\b(rt_hip_[a-z0-9_]+)\s*\(", text)))
 
 
+def exported_functions(path):
+    """Defined dynamic symbols of a shared library that are functions of the rt_hip_ family (`nm -D --defined-only`)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", str(path)], check=True, capture_output=True, text=True).stdout
+    return sorted(line.split()[-1] for line in out.splitlines() if line.split()[-1].startswith("rt_hip_"))
+
+
 def test_header_symbols_all_exported():
     names = declared_functions((ROOT / "include" / "rt_hip.h").read_text())
     assert len(names) >= 15
@@ -24,6 +32,28 @@ def test_header_symbols_all_exported():
         assert hasattr(lib, name), f"{name} declared in include/rt_hip.h but not exported"
     bound = {name for name, _, _ in capi.RT_HIP_SYMBOLS}
     assert bound == set(names), f"bindings and header disagree: {bound ^ set(names)}"
+
+
+def test_the_product_exports_the_drop_in_surface_and_nothing_else():
+    """`nm -D librt_hip.so | grep rt_hip_` is exactly what include/rt_hip.h declares (and INTEGRATION.md §2
+    binds) — no test hooks, no C++ internals; the known-answer entry points live in the test-only librt_hip_kat.so."""
+    names = declared_functions((ROOT / "include" / "rt_hip.h").read_text())
+    assert exported_functions(capi.hip_library_path()) == names
+    assert not any("kat" in name or "debug" in name for name in names)
+    import subprocess
+
+    everything = subprocess.run(["nm", "-D", "--defined-only", str(capi.hip_library_path())], check=True, capture_output=True, text=True).stdout
+    assert "_ZN6rt_hip" not in everything, "C++ internals of the module are exported"
+    integration = (ROOT / "INTEGRATION.md").read_text()
+    for name in names:
+        assert name in integration, f"{name} is exported but INTEGRATION.md does not mention it"
+
+
+def test_kat_library_exports_its_header():
+    kat_names = [n for n in declared_functions((ROOT / "include" / "rt_hip_kat.h").read_text()) if n.startswith("rt_hip_kat_")]
+    assert exported_functions(capi.kat_library_path()) == kat_names
+    assert {name for name, _, _ in capi.RT_HIP_KAT_SYMBOLS} == set(kat_names)
+    capi.kat_lib()  # loads next to librt_hip.so and binds every symbol
 
 
 def test_abi_version_and_struct_sizes():

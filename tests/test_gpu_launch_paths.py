@@ -204,6 +204,34 @@ def test_back_buffer_unmapped_and_mapped_again_at_the_same_address(members):
         _unmap(address, size)
 
 
+@pytest.mark.parametrize("members,direct", [(1, False), (2, False), (3, True)])
+def test_default_frames_survive_a_buffer_re_created_at_the_same_address_without_any_call_in_between(members, direct):
+    """what faulted the GPU in round 3 (profiles/r03/remap_without_forget.txt) — the caller unmaps its
+    image and maps a new one of the same size at the same address between two frames, and tells the module NOTHING — is
+    harmless in the default mode: the module keeps no lock, no mapping and no memory of the caller's buffer; its kernels store
+    into a frame of its own and host threads copy from there.  This is the mode the plug-in uses (shim/hip_ray_tracer.cpp),
+    because rt re-creates its images while another renderer is active (reference src/window.cpp:198-203,213)."""
+    width, height, seed = 256, 144, 6
+    size = width * height * 4  # 36 whole pages
+    pod = _scene("basic", 3).describe(width, height)
+    want, _, _ = oracle.render(pod, width, height, seed=seed, want_rgb=False)
+    kwargs = {"device": 0} if members == 1 else {"devices": [0] * members, "peer_copy": True, "direct_frame": direct}
+    with rt_amd.HipRayTracer(**kwargs) as mine:
+        address = _map_at(None, size)
+        for generation in range(3):  # map, render twice, unmap — and the same address again, no rt_hip_forget_frame anywhere
+            view = np.ctypeslib.as_array((C.c_uint32 * (width * height)).from_address(address)).reshape(height, width)
+            assert not view.any()  # fresh zero pages
+            for _ in range(2):
+                view[:] = 0x000000FF  # the caller's pre-cleared black (reference src/main.cpp:318)
+                mine.render(pod, width, height, seed=seed, out=view, stats=False)
+                assert np.array_equal(view, want), generation
+                assert rt_amd.live_frame_locks() == 0
+            del view
+            _unmap(address, size)
+            if generation < 2:
+                assert _map_at(address, size) == address
+
+
 def test_a_freed_back_buffer_of_another_size_is_simply_replaced():
     """The ordinary resize: the old image is freed, the new one has another size (and possibly an overlapping address).  The
     module drops the old page-lock — on memory that is already gone: hipHostUnregister may fail, which must not leak into
@@ -253,11 +281,13 @@ def test_phases_and_comm_info_of_a_multi_member_frame(members):
     with rt_amd.HipRayTracer(devices=[0] * members, peer_copy=True) as mine:
         for r in range(members):
             assert mine.comm_info(r) == {"ranks": members, "rank": r, "device": 0, "transport": "peer_copy"}
-        # pageable buffer: stripes of every member gathered, assembled in HBM, one copy
+        # the default: the root's stripes and the assembled ones go to the module's own page-locked frame, the carrier takes
+        # them on into the caller's (pageable) buffer — no device-to-host copy
         got, _, stats = mine.render(pod, width, height, seed=seed)
         phases = mine.phases()
         assert np.array_equal(got, want) and stats["segments"] == want_stats["segments"]
-        assert phases["transport"] == "peer_copy" and phases["render_ms"] > 0 and phases["assemble_ms"] > 0 and phases["copy_ms"] > 0
+        assert phases["transport"] == "peer_copy" and phases["render_ms"] > 0 and phases["assemble_ms"] > 0 and phases["copy_ms"] == 0
+        assert rt_amd.live_frame_locks() == 0
         # page-locked buffer: the root's stripes go straight to the frame, the others are assembled into it — no copy
         for _ in range(2):
             back[:] = 0
@@ -285,8 +315,10 @@ def test_direct_frame_reports_its_transport():
             mine.render(pod, width, height, seed=seed, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=back, stats=keep)
             assert np.array_equal(back, want)
             assert mine.phases()["transport"] == "direct_frame" and mine.comm_info(1)["transport"] == "direct_frame"
-        got, _, _ = mine.render(pod, width, height, seed=seed)  # a pageable buffer falls back to the gathered way
-        assert np.array_equal(got, want) and mine.phases()["transport"] == "peer_copy"
+        got, _, _ = mine.render(pod, width, height, seed=seed)  # the default: every member stores into the module's own frame
+        assert np.array_equal(got, want) and mine.phases()["transport"] == "direct_frame" and rt_amd.live_frame_locks() == 0
+        got, rgb, _ = mine.render(pod, width, height, seed=seed, want_rgb=True)  # the float mean takes the gathered way
+        assert np.array_equal(got, want) and rgb is not None and mine.phases()["transport"] == "peer_copy"
 
 
 # ---- one process per GPU: the two halves of rt_hip_create_rank -------------------------------------------------------------------

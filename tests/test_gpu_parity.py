@@ -311,9 +311,10 @@ def test_persistent_back_buffer_and_unchanged_scene_take_the_fast_path_and_stay_
     tracer.render(pod3, width, height // 2, seed=3, out=other, flags=PERSISTENT)
     want3, _, _ = oracle.render(pod3, width, height // 2, seed=3, want_rgb=False)
     assert np.array_equal(other, want3)
-    # and a call without the flag releases the registration again
+    assert rt_amd.live_frame_locks() == 1
+    # and a call without the flag releases the registration again (the module's own frame and its carrier take over)
     tracer.render(pod3, width, height // 2, seed=3, out=other)
-    assert np.array_equal(other, want3)
+    assert np.array_equal(other, want3) and rt_amd.live_frame_locks() == 0
 
 
 def test_seed_changes_the_image_and_equal_seeds_repeat_it(tracer):
@@ -631,8 +632,8 @@ def test_rendering_straight_into_the_page_locked_back_buffer(tracer):
     tracer.render(small, 64, 40, seed=3, flags=flag, out=other)
     assert np.array_equal(other, want_small)
     back[:] = 0
-    tracer.render(pod, 333, 187, seed=2, out=back)  # no flag: staged copy, registration dropped
-    assert np.array_equal(back, want)
+    tracer.render(pod, 333, 187, seed=2, out=back)  # no flag: the module's own frame, registration dropped
+    assert np.array_equal(back, want) and rt_amd.live_frame_locks() == 0
     view = np.zeros((187 + 2, 333), dtype=np.uint32)[1:-1]  # a buffer that does not start on a page boundary
     tracer.render(pod, 333, 187, seed=2, flags=flag, out=view)
     assert np.array_equal(view, want)
@@ -654,27 +655,20 @@ def test_noise_statistics_at_1080p_match_independent_generators(tracer):
         pytest.skip("the mt19937 model of a 1080p x 16 spp frame wants a many-core host (the GPU boxes have 256 threads)")
     width, height = 1920, 1080
     scene = rt_amd.Scene.named("basic")
-    import warnings
+    def checked(img, name):
+        """The radiance of this scene is <= 1.  In round 3 ONE run of this test found float64 garbage in `truth` — bytes of packed
+        RGBA8 pixels in an array no render writes to (DESIGN.md §9 has the analysis; the module has handed the HIP runtime no
+        caller memory since).  No second chance: the first wild value fails the test and says where it is."""
+        wild = np.argwhere(~(np.abs(img) < 4.0).all(axis=-1))
+        assert len(wild) == 0, (f"{name}: {len(wild)} pixels outside [0, 4); first at (y, x) = {wild[:8].tolist()}, values {img[tuple(wild[0])]}, "
+                                f"bytes {img[tuple(wild[0])].tobytes().hex()}, byte offset {int((wild[0][0] * width + wild[0][1]) * 3 * img.itemsize)} of the array at {img.ctypes.data:#x}")
+        return img
 
-    def sane(make, name):
-        """The radiance of this scene is <= 1.  One full-suite run in six of round 3 found float64 garbage in `truth` — bytes that
-        look like packed RGBA8 pixels, in an array no render writes to — and neither 400 rounds of tools/gpu_pageable_stress.py nor
-        three more full runs reproduced it.  This test is about random streams, not about that: a broken buffer is rendered
-        again, loudly."""
-        for attempt in range(2):
-            img = make()
-            wild = np.argwhere(~(np.abs(img) < 4.0).all(axis=-1))
-            if len(wild) == 0:
-                return img
-            warnings.warn(f"{name}: {len(wild)} pixels outside [0, 4) (attempt {attempt}); first at (y, x) = {wild[:8].tolist()}, values {img[tuple(wild[0])]}, "
-                          f"byte offset {int((wild[0][0] * width + wild[0][1]) * 3 * img.itemsize)}")
-        raise AssertionError(f"{name}: still broken after rendering it again")
-
-    truth = sane(lambda: tracer.render(scene.set_sampling(1024).describe(width, height), width, height, seed=99, want_rgb=True)[1].astype(np.float64), "truth")
+    truth = checked(tracer.render(scene.set_sampling(1024).describe(width, height), width, height, seed=99, want_rgb=True)[1].astype(np.float64), "truth")
     pod = scene.set_sampling(16).describe(width, height)
-    ours = sane(lambda: tracer.render(pod, width, height, seed=5, want_rgb=True)[1].astype(np.float64), "ours")
-    model = sane(lambda: oracle.render_mt19937(pod, width, height, fixed_seed=77, want_rgb=True)[1].astype(np.float64), "model")
-    assert (np.abs(truth) < 4.0).all()  # (and nothing rendered later wrote into it)
+    ours = checked(tracer.render(pod, width, height, seed=5, want_rgb=True)[1].astype(np.float64), "ours")
+    model = checked(oracle.render_mt19937(pod, width, height, fixed_seed=77, want_rgb=True)[1].astype(np.float64), "model")
+    checked(truth, "truth, after the later renders")  # (nothing rendered later wrote into it)
 
     def noise(img):
         err = (img - truth)[..., 0]  # red channel: ground, sky and both spheres all show in it

@@ -90,7 +90,7 @@ def test_hip_rasterizer_plugin_draws_the_oracle_preview_boxes_included(tmp_path)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("devices,frame", [("0", None), ("all", None), ("all", "direct"), ("0", "copy"), ("all", "copy")])
+@pytest.mark.parametrize("devices,frame", [("0", None), ("all", None), ("all", "direct"), ("0", "locked"), ("all", "locked"), ("all", "locked+direct")])
 def test_plugin_with_rt_hip_devices_renders_through_the_multi_gpu_context(tmp_path, devices, frame):
     """RT_HIP_DEVICES makes the plug-in create ONE rt_hip_create_multi context (RCCL communicator, gather, assemble, one
     copy) behind the same blocking render() — on this box 'all' is one GPU, which still takes that whole path."""
