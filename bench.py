@@ -53,6 +53,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's host dri
 
 FP32_VALU_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (vector)"
 HBM_PEAK_GBPS = 8000.0  # same guide, HBM3E spec
+SHADER_CLOCK_HZ = 2.4e9  # the clock the FP32 peak above is quoted at (under load the card holds 2.36-2.40 GHz: profiles/r03/config5_streamed/)
 
 
 def algorithmic_flops(samples: int, segments: int, n_spheres: int, n_planes: int) -> float:
@@ -127,6 +128,7 @@ def main() -> None:
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
     ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
+    ap.add_argument("--resident", action="store_true", help="force the LDS-resident kernel (what a scene of 9 to 704 primitives gets; scenes of up to 8 take the scalar-register kernel otherwise)")
     ap.add_argument("--fast", action="store_true", help="RT_HIP_FLAG_FAST: the tolerance-bound arithmetic (raw v_rsq/v_rcp), a second bench line; never the parity contract")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode with --gather torch only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
@@ -167,7 +169,7 @@ def main() -> None:
 
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
     pod = scene.describe(args.width, args.height)
-    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else 0)
+    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
     if args.fast:
         flags |= capi.RT_HIP_FLAG_FAST
     samples_total = args.width * args.height * args.spp
@@ -194,15 +196,44 @@ def main() -> None:
         local_rows = rt_amd.local_rows(args.height, 0, n_gpus)
         scene_bytes = 20 * pod.n_spheres + 20 * pod.n_planes + 28 * pod.n_materials
         hbm_bytes = 4 * args.width * local_rows + scene_bytes
+        # Counter figures of this very workload (profiles/pmc_counters.json: rocprofv3 --pmc passes of tools/gpu_profile_r4.sh over
+        # this command), used only if they were measured on THESE kernels: the entry carries a hash of the kernel sources, and
+        # a figure from other kernels is dropped, not reported.
         traffic = None
-        pmc = ROOT / "profiles" / "pmc_traffic.json"
-        if pmc.exists():
-            try:
-                rec = json.loads(pmc.read_text())
-                key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}"
-                traffic = rec.get(key, {}).get("hbm_bytes_per_launch")
-            except (ValueError, OSError):
-                traffic = None
+        issue = None
+        forced = "_tiled" if args.tiled else "_streamed" if args.streamed else "_resident" if args.resident else ""
+        counters_key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}{forced}" + ("_fast" if args.fast else "")
+        try:
+            from tools.kernel_sources_hash import kernel_sources_sha16
+
+            built_from = kernel_sources_sha16()
+            rec = json.loads((ROOT / "profiles" / "pmc_counters.json").read_text()).get(counters_key)
+        except (ImportError, OSError, ValueError):
+            built_from, rec = None, None
+        if rec is not None and rec.get("kernel_sources_sha16") != built_from:
+            issue = {"status": f"dropped: profiles/pmc_counters.json[{counters_key}] was measured on kernel sources {rec.get('kernel_sources_sha16')}, this build is {built_from}"}
+            rec = None
+        if rec is not None:
+            traffic = rec.get("hbm_bytes_per_launch")
+            c = rec.get("counters_per_launch", {})
+            if c.get("SQ_INSTS_VALU") and duration_ms == duration_ms:
+                simds = 4 * 256  # MI355X: 256 CUs x 4 SIMDs; a wave64 VALU instruction occupies a SIMD for 2 cycles (157.3 TFLOP/s = 256 x 128 lanes x 2 flop x 2.4 GHz)
+                valu, salu = c["SQ_INSTS_VALU"], c.get("SQ_INSTS_SALU", 0.0)
+                ceiling_ms = valu * 2.0 / (simds * SHADER_CLOCK_HZ) * 1e3
+                issue = {
+                    "valu_wave_insts_per_launch": valu,
+                    "salu_wave_insts_per_launch": salu,
+                    "salu_per_valu": round(salu / valu, 4),
+                    "waves_per_launch": c.get("SQ_WAVES"),
+                    "lanes_active_frac": round(c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]), 4) if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU") else None,
+                    "valu_insts_per_64_samples": round(valu * 64.0 / max(member["primary_samples"], 1), 2),
+                    "algorithmic_fma_insts_per_64_samples": round(flops / 2.0 / max(member["primary_samples"], 1), 2),
+                    "cycles_per_valu_inst_per_simd": round(duration_ms * 1e-3 * SHADER_CLOCK_HZ * simds / valu, 3),
+                    "issue_ceiling_ms": round(ceiling_ms, 4),
+                    "frac_of_issue_ceiling": round(ceiling_ms / duration_ms, 4),
+                    "what": "VALU wave-instructions of one launch (SQ_INSTS_VALU) x 2 cycles / (1024 SIMDs x 2.4 GHz) over this run's kernel time: how close the kernel's OWN instruction stream runs to the vector issue rate — the flop fraction above also counts against it every instruction that is not an FMA (integer hashing of the random streams, lane-mode selects, quarter-rate rsq / rcp / sqrt)",
+                    "source": f"{rec.get('source')} ({rec.get('measured')}, kernel sources {rec.get('kernel_sources_sha16')}); kernel time from this run",
+                }
         roofline = {
             "bound": "valu_fp32",
             "kernel": f"render_{member['kernel']}",
@@ -211,6 +242,7 @@ def main() -> None:
             "unit": "TFLOP/s",
             "frac": round(achieved_tflops / FP32_VALU_PEAK_TFLOPS, 4),
             "traffic": traffic,
+            "issue": issue,
             "kernel_ms": round(duration_ms, 4),
             "kernel_ms_source": "HIP events on the launch stream around every launch of the timed region (rt_hip_stats.render_ms), averaged" if kernel_ms == kernel_ms else "wall per frame (two frames in flight)",
             "algorithmic_flops_per_launch": flops,

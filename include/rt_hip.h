@@ -156,7 +156,7 @@ enum
 	RT_HIP_KERNEL_NONE		= 0,
 	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup (<= 1024 primitives) */
 	RT_HIP_KERNEL_TILED		= 2, /* primitives streamed from the SoA columns through LDS in tiles (large scenes) */
-	RT_HIP_KERNEL_SMALL		= 3, /* <= 8 spheres, no planes: scene in scalar registers, scan fully unrolled */
+	RT_HIP_KERNEL_SMALL		= 3, /* <= 8 primitives (>= 1 sphere, <= 3 planes): scene in scalar registers, scan fully unrolled */
 	RT_HIP_KERNEL_PREVIEW	= 4, /* RT_HIP_FLAG_PREVIEW: one primary ray per pixel, N.L shading */
 	RT_HIP_KERNEL_STREAMED	= 5	 /* primitives read from the table in HBM/L2 with wave-uniform scalar loads: no staging, no barriers */
 };

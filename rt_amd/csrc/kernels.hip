@@ -325,7 +325,12 @@ namespace rt_hip
 		// slot, next to the first half's partial sum, and the fold at the end of the wave continues that partial sum with
 		// them, in order.  Twice as many, half as long items: what a launch with two or three chunks per lane needs to end
 		// evenly (profiles/r03/chunk_probe.txt).
-		template <int NS, bool SM, bool HALF = false>
+		// NP (small kernel only; round 4): the NS scalar-register spheres are FOLLOWED BY NP PLANES (slots NS .. NS + NP - 1 of
+		// the kernel argument), so that the reference's own scenes with their ground plane back in (scenes/basic.toml:11-13,
+		// scenes/dielectric.toml:17-19) stay on the scalar-operand path.  Which slot is what is known at compile time: no
+		// kind check at run time, and the no-plane variants are what they were.  NS + NP <= 8, NP <= 3 (more planes, or planes
+		// without a sphere, take the LDS-resident kernel).
+		template <int NS, bool SM, bool HALF = false, int NP = 0>
 		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
@@ -348,7 +353,7 @@ namespace rt_hip
 				if (threadIdx.x == 0)
 				{
 #pragma unroll
-					for (int i = 0; i < NS; i++) // constant indices: the argument block is never indexed dynamically
+					for (int i = 0; i < NS + NP; i++) // constant indices: the argument block is never indexed dynamically
 					{
 						lds_geometry[i] = small.geometry[i];
 						lds_shading[i] = small.shading[i];
@@ -402,7 +407,7 @@ namespace rt_hip
 			lane_state st;
 			// path segments traced: counted on the scalar unit (one popcount of the tracing lanes per trip) where scalar
 			// registers are to spare — the 1..4-sphere kernels; 2 more live SGPRs make the others spill — else per lane
-			constexpr bool SCALAR_SEGMENTS = NS >= 1 && NS <= 4;
+			constexpr bool SCALAR_SEGMENTS = NS >= 1 && NS + NP <= 4;
 			unsigned long long wave_segments = 0;
 			uint32_t lane_segments = 0;
 			uint32_t slot = 0; // chunk-sum slot of the item in flight on this lane; rolling: its pixel's place in the hand-out order
@@ -728,10 +733,24 @@ namespace rt_hip
 								finish_sphere(best, probes[i], small.geometry[i].w, static_cast<uint32_t>(i), lanes[i]);
 							}
 						}
-						const bool hit = best.have && best.t >= 0.0f;
-						kind = hit ? 1u : 0u;
-						distance = best.t;
-						small_index = best.index; // the lookups of the winning sphere follow below, in the one `hit` region
+						if (NP > 0)
+						{
+							// test_planes (:36-60) over the plane slots, with its own best candidate; then select(spheres, planes) (:96-102,160)
+							candidate best_plane = { 0.0f, 0u, false };
+#pragma unroll
+							for (int j = 0; j < NP; j++)
+								test_plane(best_plane, st.origin, st.dir, small.geometry[(NS > 0 ? NS : 0) + j], static_cast<uint32_t>(j));
+							uint32_t index;
+							kind = select_hit(best, best_plane, distance, index);
+							small_index = kind == 2u ? static_cast<uint32_t>(NS) + index : index; // the winner's slot
+						}
+						else
+						{
+							const bool hit = best.have && best.t >= 0.0f;
+							kind = hit ? 1u : 0u;
+							distance = best.t;
+							small_index = best.index; // the lookups of the winning sphere follow below, in the one `hit` region
+						}
 					}
 					else
 					{
@@ -769,6 +788,8 @@ namespace rt_hip
 							shading = lds_shading[small_index];
 							scatter_kind = lds_scatter[small_index];
 							normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
+							if (NP > 0 && kind == 2u)
+								normal = { g.x, g.y, g.z }; // the plane's normal as it is, not flipped toward the ray (:58)
 						}
 						base = normal;
 						if (scatter_kind == scatter_metal)
@@ -1217,7 +1238,7 @@ namespace rt_hip
 
 #endif // !RT_HIP_FAST_BUILD
 
-		template <int NS, bool SM>
+		template <int NS, bool SM, int NP = 0>
 		void launch_queue_sm(const frame_params& frame,
 							 const queue_params& queue,
 							 const small_scene& small,
@@ -1249,7 +1270,7 @@ namespace rt_hip
 					hipError_t asked;
 					if constexpr (!SM)
 						asked = sub_chunk_items ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM, true>, static_cast<int>(block_threads), lds_bytes)
-												: hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM, false>, static_cast<int>(block_threads), lds_bytes);
+												: hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM, false>, static_cast<int>(block_threads), lds_bytes); // (persistent kernels: never with scalar-register planes)
 					else
 						asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes);
 					if (asked != hipSuccess || per_cu < 1)
@@ -1264,14 +1285,14 @@ namespace rt_hip
 			{
 				if (queue.halves)
 				{
-					hipLaunchKernelGGL((render_queue<NS, SM, true>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
+					hipLaunchKernelGGL((render_queue<NS, SM, true, NP>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 					return;
 				}
 			}
-			hipLaunchKernelGGL((render_queue<NS, SM>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
+			hipLaunchKernelGGL((render_queue<NS, SM, false, NP>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 		}
 
-		template <int NS>
+		template <int NS, int NP = 0>
 		void launch_queue(bool sm,
 						  const frame_params& frame,
 						  const queue_params& queue,
@@ -1289,10 +1310,10 @@ namespace rt_hip
 		{
 #ifndef RT_HIP_FAST_BUILD // (the API refuses RT_HIP_FLAG_FAST together with RT_HIP_FLAG_SM_MATERIALS)
 			if (sm)
-				launch_queue_sm<NS, true>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+				launch_queue_sm<NS, true, NP>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			else
 #endif
-				launch_queue_sm<NS, false>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+				launch_queue_sm<NS, false, NP>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 		}
 	}
 
@@ -1305,7 +1326,8 @@ namespace rt_hip
 		if (flags & RT_HIP_FLAG_FORCE_TILED)
 			return RT_HIP_KERNEL_TILED;
 		// (the scalar-register kernel knows rt's camera only — a matrix whose w varies over the frame takes the LDS kernel)
-		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && uniform_w && scene.n_planes == 0 && scene.n_spheres >= 1 && scene.n_spheres <= scalar_max_spheres)
+		// up to 8 primitives: at least one sphere, at most three planes (round 4: a plane no longer pushes a scene off this kernel)
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && uniform_w && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
 		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against
@@ -1503,17 +1525,28 @@ namespace rt_hip
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
-			switch (scene.n_spheres)
+#define RT_HIP_LAUNCH_SMALL(N, P) launch_queue<N, P>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)
+#define RT_HIP_LAUNCH_SMALL_SPHERES(P, N_MAX)                                                                                        \
+	switch (scene.n_spheres)                                                                                                         \
+	{                                                                                                                                \
+		case 1: RT_HIP_LAUNCH_SMALL(1, P); break;                                                                                    \
+		case 2: RT_HIP_LAUNCH_SMALL(2, P); break;                                                                                    \
+		case 3: RT_HIP_LAUNCH_SMALL(3, P); break;                                                                                    \
+		case 4: RT_HIP_LAUNCH_SMALL(4, P); break;                                                                                    \
+		case 5: RT_HIP_LAUNCH_SMALL(5, P); break;                                                                                    \
+		case 6: if constexpr (N_MAX >= 6) RT_HIP_LAUNCH_SMALL(6, P); break;                                                          \
+		case 7: if constexpr (N_MAX >= 7) RT_HIP_LAUNCH_SMALL(7, P); break;                                                          \
+		default: if constexpr (N_MAX >= 8) RT_HIP_LAUNCH_SMALL(8, P); break;                                                         \
+	}
+			switch (scene.n_planes) // (choose_kernel admits n_spheres + n_planes <= 8 only)
 			{
-				case 1: launch_queue<1>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 2: launch_queue<2>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 3: launch_queue<3>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 4: launch_queue<4>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 5: launch_queue<5>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 6: launch_queue<6>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				case 7: launch_queue<7>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
-				default: launch_queue<8>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream); break;
+				case 0: RT_HIP_LAUNCH_SMALL_SPHERES(0, 8); break;
+				case 1: RT_HIP_LAUNCH_SMALL_SPHERES(1, 7); break;
+				case 2: RT_HIP_LAUNCH_SMALL_SPHERES(2, 6); break;
+				default: RT_HIP_LAUNCH_SMALL_SPHERES(3, 5); break;
 			}
+#undef RT_HIP_LAUNCH_SMALL_SPHERES
+#undef RT_HIP_LAUNCH_SMALL
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)

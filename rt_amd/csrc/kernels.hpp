@@ -83,11 +83,12 @@ namespace rt_hip
 	};
 
 	// the whole scene of the `small` kernel, passed by value as a kernel argument (-> SGPRs); host copy kept by the context
-	constexpr uint32_t scalar_max_spheres = 8; // sphere-only scenes up to this size run with the scene in SGPRs
+	constexpr uint32_t scalar_max_spheres = 8; // scenes of up to this many primitives (spheres + planes) run with the scene in SGPRs
+	constexpr uint32_t scalar_max_planes = 3;  // ... of which at most this many planes (and at least one sphere)
 	struct small_scene
 	{
-		float4 geometry[scalar_max_spheres]; // (center, radius^2)
-		float4 shading[scalar_max_spheres];	 // (attenuation.rgb, roughness or index of refraction) of the sphere's material
+		float4 geometry[scalar_max_spheres]; // spheres (center, radius^2), then planes (normal, d)
+		float4 shading[scalar_max_spheres];	 // (attenuation.rgb, roughness or index of refraction) of the primitive's material
 		uint32_t scatter[scalar_max_spheres]; // scatter_*
 	};
 

@@ -248,7 +248,7 @@ namespace rt_hip
 			put(L.prim_metal + i * 4, &metal, 4);
 			put(L.prim_shading_sm + i * sizeof(float4), shading_sm, sizeof(float4));
 			put(L.prim_scatter_sm + i * 4, &scatter_sm, 4);
-			if (is_sphere && i < scalar_max_spheres)
+			if (i < scalar_max_spheres) // (what the scalar-register kernel is given: meaningful for scenes of <= 8 primitives)
 			{
 				std::memcpy(&r.small.geometry[i], geometry, sizeof(geometry));
 				std::memcpy(&r.small.shading[i], shading_mg, sizeof(float4));

@@ -286,7 +286,7 @@ def test_phases_and_comm_info_of_a_multi_member_frame(members):
         got, _, stats = mine.render(pod, width, height, seed=seed)
         phases = mine.phases()
         assert np.array_equal(got, want) and stats["segments"] == want_stats["segments"]
-        assert phases["transport"] == "peer_copy" and phases["render_ms"] > 0 and phases["assemble_ms"] > 0 and phases["copy_ms"] == 0
+        assert phases["transport"] == "peer_copy" and phases["render_ms"] > 0 and phases["assemble_ms"] > 0 and phases["copy_ms"] < 0.05  # (two event records apart: nothing is copied)
         assert rt_amd.live_frame_locks() == 0
         # page-locked buffer: the root's stripes go straight to the frame, the others are assembled into it — no copy
         for _ in range(2):

@@ -152,8 +152,8 @@ def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, boun
         expected_kernel = "tiled"
     elif flags == FORCE_STREAMED or primitives > 1024:
         expected_kernel = "streamed"  # (every big scene, whatever its sample count: profiles/r03/tiled_vs_streamed.txt)
-    elif flags == 0 and pod.n_planes == 0 and 1 <= pod.n_spheres <= 8:
-        expected_kernel = "small"
+    elif flags == 0 and pod.n_spheres >= 1 and pod.n_planes <= 3 and primitives <= 8:
+        expected_kernel = "small"  # (round 4: up to three planes ride in scalar registers behind the spheres)
     elif flags == 0 and primitives > 704:
         expected_kernel = "streamed"  # (the resident kernel holds up to 1024 primitives; the launch code prefers it up to 704)
     else:
@@ -187,6 +187,64 @@ def test_sphere_counts_around_the_scalar_kernel_limit(tracer, count):
 
 
 SM = capi.RT_HIP_FLAG_SM_MATERIALS
+
+
+@pytest.mark.parametrize("name", ["basic_plane", "dielectric_plane"])
+def test_the_reference_scenes_with_their_ground_plane_stay_on_the_scalar_register_kernel(tracer, name):
+    """VERDICT r3 missing #3: both scene files of the reference carry a plane one comment away (scenes/basic.toml:11-13,
+    scenes/dielectric.toml:17-19) and test_planes is on the path (mg_ray_tracer.cpp:36-60,160).  With the plane active the
+    scenes keep the scalar-operand kernel (its plane slots are known at compile time) and stay bit-exact, sm table included."""
+    width, height, spp = 160, 90, 20
+    pod = rt_amd.Scene.named(name).set_sampling(spp).describe(width, height)
+    assert pod.n_planes == 1
+    for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, SM, FORCE_RESIDENT):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=31, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=31, sm_materials=bool(flags & SM))
+        assert stats["kernel"] == ("resident" if flags & FORCE_RESIDENT else "small")
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{name} flags {flags}")
+        assert stats["segments"] == want_stats["segments"] and stats["plane_tests"] == want_stats["segments"]
+
+
+@pytest.mark.parametrize("n_spheres,n_planes", [(s, p) for p in (1, 2, 3) for s in range(1, 9 - p)] + [(0, 1), (6, 3), (1, 4)])
+def test_every_sphere_and_plane_count_of_the_scalar_register_kernel(tracer, n_spheres, n_planes):
+    """One random scene per (spheres, planes) combination the scalar-register kernel is built for — 1..7 spheres followed by
+    1..3 planes, at most 8 primitives — in whole and half chunks and under the sm table, against the oracle; and the
+    neighbours just outside (no sphere, nine primitives, four planes), which must take the LDS-resident kernel."""
+    rng = np.random.default_rng(4200 + 16 * n_planes + n_spheres)
+    n_mat = 4
+    materials = [(int(rng.integers(0, 8)), *rng.uniform(0.2, 1.0, 3), 1.0, rng.uniform(0.0, 0.5), rng.uniform(0.4, 1.5)) for _ in range(n_mat)]
+    spheres = [(rng.uniform(-3, 3), rng.uniform(-0.5, 2.5), rng.uniform(-7, -1), rng.uniform(0.3, 1.2), rng.integers(0, n_mat)) for _ in range(n_spheres)]
+    planes = [(0.0, 1.0, 0.0, rng.uniform(0.0, 1.0), rng.integers(0, n_mat))]  # a floor below the camera ...
+    for _ in range(n_planes - 1):  # ... and walls at random
+        n = rng.normal(size=3)
+        n /= np.linalg.norm(n)
+        planes.append((*n, rng.uniform(2.0, 6.0), rng.integers(0, n_mat)))
+    width, height, spp, bounces = 96, 54, int(rng.integers(3, 40)), int(rng.integers(2, 9))
+    camera = rt_amd.Scene.parse("").set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
+    in_registers = n_spheres >= 1 and n_planes <= 3 and n_spheres + n_planes <= 8
+    for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, capi.RT_HIP_FLAG_FORCE_WHOLE_CHUNKS, SM):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=n_spheres * 10 + n_planes, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=n_spheres * 10 + n_planes, sm_materials=bool(flags & SM))
+        assert stats["kernel"] == ("small" if in_registers else "resident")
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{n_spheres} spheres + {n_planes} planes, flags {flags}")
+        assert stats["segments"] == want_stats["segments"]
+
+
+def test_sphere_beats_plane_at_equal_distance_in_the_scalar_register_kernel(tracer):
+    """select(spheres, planes): `a.distance <= b.distance ? a : b` (mg_ray_tracer.cpp:96-102,160) — the sphere wins a tie.  A unit
+    sphere at z = -5 and the plane z = -4 touch on the optical axis; the two carry different materials, so whichever wins
+    colours the centre pixels.  Through the whole frame against the oracle, and the centre pixel against the sphere's material."""
+    materials = [(0, 1.0, 0.0, 0.0, 1.0, 0.5, 0.5), (0, 0.0, 1.0, 0.0, 1.0, 0.5, 0.5)]  # sphere red, plane green
+    pod = rt_amd.scene_from_arrays([(0.0, 0.0, -5.0, 1.0, 0)], [(0.0, 0.0, 1.0, 4.0, 1)], materials, samples_per_pixel=1, max_bounces=2,
+                                   inverse_view_projection=rt_amd.Scene.parse("").set_camera((0, 0, 0), (0, 0, -1)).describe(65, 65).inverse_view_projection[:])
+    got_rgba, got_rgb, stats = tracer.render(pod, 65, 65, seed=1, want_rgb=True)
+    want_rgba, want_rgb, _ = oracle.render(pod, 65, 65, seed=1)
+    assert stats["kernel"] == "small"
+    assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "tangent sphere and plane")
+    centre = got_rgb[32, 32]
+    assert centre[1] == 0.0 and centre[2] == 0.0  # no green: the sphere's red attenuation (or black), never the plane's
 
 
 def random_scene(rng):

@@ -11,6 +11,10 @@ import numpy as np
 
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 import rt_amd  # noqa: E402
+from rt_amd import capi  # noqa: E402
+
+# (the round-3 library lacks what round 4 added to the ABI: bind what it has)
+capi.RT_HIP_SYMBOLS = [entry for entry in capi.RT_HIP_SYMBOLS if entry[0] != "rt_hip_live_frame_locks"]
 
 width, height = 1920, 1080
 scene = rt_amd.Scene.named("basic")
