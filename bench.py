@@ -12,38 +12,44 @@ scenes/basic.toml (BASELINE.json `metric`), on N MI355X of one node.
 A "step" is one whole `render(scene, back_buffer)` as the reference makes it: host scene
 columns in, finished frame in the caller's HOST buffer out, ONE frame at a time — scene fingerprint check (the columns
 were uploaded during warm-up and are not re-sent while unchanged), kernel(s), for N > 1 the RCCL gather to rank 0 and the
-de-interleave, and the transfer of the frame to the host.  `value` is that drop-in rate; the kernel-only rate (scene
-resident, frame left in HBM) is carried beside it as `kernel_only`.  The frame is fixed as N grows: scaling is STRONG.
+de-interleave, and the delivery of the frame into the caller's (pageable) back buffer.  `value` is that drop-in rate; the
+kernel-only rate (scene resident, frame left in HBM) is carried beside it as `kernel_only`.  The frame is fixed as N grows:
+scaling is STRONG.
 
-N > 1 under torchrun runs the step in THREE forms, one after the other, and says so in the line (`paths`):
-  * `torch`        — torch.distributed.gather + rt_hip_assemble_device + a copy to a pinned host frame: building blocks
-                     that every ROCm installation exercises;
-  * `shared_frame` — every process is one rank of a FRAME GROUP (rt_hip_create + rt_hip_join_frame_group): the caller's
-                     back buffer is a shared mapping every rank process maps and page-locks, and every rank's kernel
-                     stores its stripes straight into it over its own PCIe link — no data-path collective, no RCCL;
-  * `library`      — every process is one rank of the module's gathering renderer (rt_hip_create + rt_hip_join_ranks:
-                     ncclCommInitRank; one ncclGather inside librt_hip.so; the root assembles straight into its
-                     page-locked back buffer).
-The last two are the product path (rt_hip_render delivers the finished frame into rank 0's host buffer).  `value` is the
-faster of those that came up, produced the very frame the `torch` form produced, and finished (`value_from` names it);
-if neither did, `value` is the `torch` form's and `paths` says why.  The ranks vote before anything collective is
-entered, the joins have deadlines, and a watchdog turns a hang of either form into the best line so far instead of a
-lost run.  Every N > 1 line carries what the transport reports about itself (`rccl`), every rank's own kernel time
-(`per_rank`) and rank 0's split of a step (`drop_in_breakdown`).
+N > 1 under torchrun (round 4).  The step exists in three forms:
+  * `library`      — THE ONE north_star NAMES, and `value` whenever it came up: every process is one rank of the module's
+                     gathering renderer (rt_hip_create + rt_hip_join_ranks: ncclCommInitRank; ONE ncclGather over xGMI
+                     inside librt_hip.so; rank 0 assembles into its frame and delivers it to its caller's back buffer);
+  * `shared_frame` — side key: every process is one rank of a FRAME GROUP (rt_hip_join_frame_group): rank 0's back buffer
+                     is a shared mapping every rank process maps and page-locks, every rank's kernel stores its stripes
+                     straight into it over its own PCIe link — no data-path collective, no RCCL;
+  * `torch`        — side key: torch.distributed.gather + rt_hip_assemble_device + a copy to a pinned host frame: building
+                     blocks that every ROCm installation exercises.
+Each form runs in a CHILD PROCESS OF ITS OWN per rank, started by this (torchrun-launched) process BEFORE anything has
+touched a GPU: one form = one context and at most one communicator per GPU, all of it gone when the child exits; a form that
+does not come back within its deadline is killed (the exact child, by pid) and reported as hung, the remaining forms still
+run, and the benchmark then EXITS NON-ZERO after printing its line.  The torchrun-launched processes themselves only keep
+a gloo group (ports, names, verdicts); they never initialise a GPU.  Inside a child the ranks vote before anything
+collective is entered and the joins have deadlines of their own; the first frame of every form must equal, bit for bit,
+the frame rank 0 renders alone on its GPU.  Every N > 1 line carries what the transport reports about itself (`rccl`: for
+the library form ncclCommCount / ncclCommUserRank / ncclCommCuDevice of every rank's communicator), every rank's own kernel
+time (`per_rank`), rank 0's split of a step (`drop_in_breakdown`) and all forms' figures and verdicts (`paths`).
 
 The `roofline` object prices the render kernel against the FP32 vector-ALU peak — the bound SURVEY.md §8d identifies for
 this path (a 3-sphere scene is ~100 bytes; the only compulsory HBM traffic is the 4 B/pixel frame) — from the kernel's
 duration measured with HIP events on its launch stream (recorded by the module around every launch of the timed region
-and read back through rt_hip_stats), and carries the HBM figures next to it.  `cpu_baseline` times the
-reference-faithful CPU model (oracle/, mt19937 mode) on a bounded sample of the same workload on this box's host cores.
+and read back through rt_hip_stats), carries the HBM figures next to it, and — `roofline.issue` — how close the kernel's
+own instruction stream runs to the vector issue rate (counter figures of profiles/pmc_counters.json, used only when they
+were measured on the kernels of this build).  `cpu_baseline` times the reference-faithful CPU model (oracle/, mt19937
+mode) on a bounded sample of the same workload on this box's host cores.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
-import threading
 import time
 from pathlib import Path
 
@@ -115,7 +121,7 @@ def spread(values: list[float]) -> dict:
     return {"kernel_ms": [round(v, 4) for v in values], "kernel_ms_min": round(min(values), 4), "kernel_ms_max": round(max(values), 4)}
 
 
-def main() -> None:
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -135,55 +141,20 @@ def main() -> None:
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: rehearsal of the N>1 flow on a box with fewer GPUs than ranks (frames staged through host memory)")
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
     ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` and `plug_in_call` side legs (profiling runs: every render launch of the process is then a step of the drop-in loop)")
-    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` (default) = the torch form first, then the module's own renderer (see the docstring), `value` from the latter when it validated; `torch` = the torch form only")
-    ap.add_argument("--library-deadline-s", type=float, default=0.0, help="watchdog of the library form under torchrun: seconds it may take in all before the torch form's line is printed instead (0 = 120 s + 50 x what the torch form took)")
+    ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` (default) = all three forms (see the docstring), `value` from the RCCL-gather form; `torch` = the torch form only")
+    ap.add_argument("--library-deadline-s", type=float, default=0.0, help="torchrun mode: seconds ONE form's child process may take before it is killed and reported as hung (0 = 180)")
+    ap.add_argument("--form", default=None, choices=["library", "shared_frame", "torch"], help="(internal) this process is the child that runs one form; started by the torchrun-launched process")
     ap.add_argument("--direct-frame", action="store_true", help="single-process N > 1 only: RT_HIP_MULTI_DIRECT_FRAME — no gather, every GPU stores its pixels straight into the page-locked back buffer")
     ap.add_argument("--locked-frame", action="store_true", help="single-process only: time the opt-in zero-copy mode (RT_HIP_FLAG_PERSISTENT_FRAME: the caller's buffer itself page-locked and mapped) as `value` instead of the default delivery through the module's own frame")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
-    args = ap.parse_args()
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
-    import torch.distributed as dist
 
+def make_build_line(args, pod, n_gpus, single_process):
+    """The contract line for one measured form (closure over the workload)."""
     import rt_amd
-    from rt_amd import capi, distributed
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    single_process = "RANK" not in os.environ  # not launched by torchrun: one process drives all --gpus devices itself
-    if not single_process and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    n_gpus = args.gpus
-
-    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(device)
-    if not single_process:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))  # "nccl" is RCCL on ROCm
-        else:
-            dist.init_process_group("gloo")
-    vote_device = "cuda" if args.backend == "nccl" else "cpu"
-
-    scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
-    pod = scene.describe(args.width, args.height)
-    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
-    if args.fast:
-        flags |= capi.RT_HIP_FLAG_FAST
     samples_total = args.width * args.height * args.spp
-
-    def fence():
-        torch.cuda.synchronize()
-        if not single_process:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def settle(render_once):
-        until = time.perf_counter() + args.settle_ms * 1e-3
-        while time.perf_counter() < until:  # untimed: brings the clocks up from idle; the W warm-up steps follow
-            render_once()
 
     def build_line(form, elapsed_s, kernels_ms, member, transport_text, more):
         ms_per_step = elapsed_s / args.steps * 1e3
@@ -193,7 +164,7 @@ def main() -> None:
         flops = algorithmic_flops(member["primary_samples"], member["segments"], pod.n_spheres, pod.n_planes)
         duration_ms = kernel_ms if kernel_ms == kernel_ms else ms_per_step  # NaN (two frames in flight): wall per frame
         achieved_tflops = flops / (duration_ms * 1e-3) / 1e12
-        local_rows = rt_amd.local_rows(args.height, 0, n_gpus)
+        local_rows = local_rows_of(args.height, 0, n_gpus)
         scene_bytes = 20 * pod.n_spheres + 20 * pod.n_planes + 28 * pod.n_materials
         hbm_bytes = 4 * args.width * local_rows + scene_bytes
         # Counter figures of this very workload (profiles/pmc_counters.json: rocprofv3 --pmc passes of tools/gpu_profile_r4.sh over
@@ -276,7 +247,7 @@ def main() -> None:
                 "kernel": member["kernel"],
                 "arithmetic": "contract v3-fast (RT_HIP_FLAG_FAST: tolerance-bound, NOT the parity contract)" if args.fast else "contract v3 (bit-exact against the oracle)",
                 "parallelism": transport_text,
-                "frames_in_flight": 1 if single_process else max(1, args.frames_in_flight if args.gather == "torch" else 1),
+                "frames_in_flight": 1,
                 "frame_mode": ("locked: the caller's back buffer page-locked and mapped, kernels store straight into it (opt-in)" if args.locked_frame else "default: kernels store into the module's own page-locked frame, host threads carry the pixels into the caller's pageable back buffer while the frame is traced") if single_process else "see parallelism",
                 "clock_settle_ms": args.settle_ms,
             },
@@ -287,10 +258,52 @@ def main() -> None:
         line.update(more)
         return line
 
+    return build_line
+
+
+def main() -> None:
+    args = parse_args()
+    single_process = "RANK" not in os.environ  # not launched by torchrun: one process drives all --gpus devices itself
+    if single_process:
+        return single_process_main(args)
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if args.form:
+        return form_main(args)
+    return forms_parent_main(args)
+
+
+def single_process_main(args) -> None:
+    import numpy as np
+    import torch
+
+    import rt_amd
+    from rt_amd import capi
+
+    single_process = True
+    n_gpus = args.gpus
+    device = 0
+    torch.cuda.set_device(device)
+    scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
+    pod = scene.describe(args.width, args.height)
+    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
+    if args.fast:
+        flags |= capi.RT_HIP_FLAG_FAST
+    samples_total = args.width * args.height * args.spp
+    build_line = make_build_line(args, pod, n_gpus, True)
+
+    def fence():
+        torch.cuda.synchronize()
+
+    def settle(render_once):
+        until = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < until:  # untimed: brings the clocks up from idle; the W warm-up steps follow
+            render_once()
+
     extras: dict = {}
     kernel_only = None
     plug_in_call = None
-    if single_process:
+    if True:
         # ---- ONE process: rt_hip_render, the drop-in call, on one context (1 GPU) or one multi-GPU context ----
         if n_gpus == 1:
             tracer = rt_amd.HipRayTracer(device=device)  # fails loudly without librt_hip.so or a gfx950 device
@@ -380,239 +393,327 @@ def main() -> None:
             kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
         tracers = [tracer]
         parallelism = "1 GPU" if n_gpus == 1 else f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, transport {transport}"
-    else:
-        # ---- one process per GPU (torchrun) ----
-        in_flight = max(1, args.frames_in_flight) if args.gather == "torch" else 1
-        padded = rt_amd.padded_local_rows(args.height, world)
-        tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
-        for t in tracers:
-            t.upload(pod)
-        scratch = torch.empty((padded, args.width), dtype=torch.int32, device=f"cuda:{device}")
 
-        def own_share():  # rank-local (no collective): this rank's own share, for the clocks
-            tracers[0].render_device(args.width, args.height, scratch.data_ptr(), seed=args.seed, flags=flags, partition=(rank, world, capi.RT_HIP_DEFAULT_STRIPE_ROWS), stream=torch.cuda.current_stream().cuda_stream)
-            torch.cuda.synchronize()
-
-        def timed(step_fn, kernel_ms_of):
-            """W warm-up steps, then exactly K steps between two fences; max over ranks; every rank's mean kernel time."""
-            for _ in range(args.warmup):
-                step_fn()
-            fence()
-            kernel_sum = 0.0
-            t_begin = time.perf_counter()
-            for _ in range(args.steps):
-                used = step_fn()
-                kernel_sum += kernel_ms_of(used)
-            fence()
-            local = time.perf_counter() - t_begin
-            t = torch.tensor([local], dtype=torch.float64, device=vote_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            kernels = [None] * world
-            dist.all_gather_object(kernels, kernel_sum / args.steps)
-            return float(t.item()), [float(k) for k in kernels]
-
-        # -- form 1: torch.distributed.gather + rt_hip_assemble_device + copy to a pinned host frame --
-        frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
-        host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
-
-        def torch_step():
-            frame = frame_maker.render(seed=args.seed, flags=flags)
-            if frame is not None:
-                host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
-            if in_flight == 1:
-                torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
-            return tracers[(frame_maker.frames - 1) % in_flight]
-
-        settle(own_share)
-        t_form = time.perf_counter()
-        torch_elapsed, torch_kernels = timed(torch_step, (lambda used: used.stats()["render_ms"]) if in_flight == 1 else (lambda used: float("nan")))
-        torch.cuda.synchronize()
-        torch_form_seconds = time.perf_counter() - t_form
-        torch_member0 = tracers[(args.steps - 1) % in_flight].stats()
-        torch_transport = "torch.distributed.gather (backend nccl = RCCL)" if args.backend == "nccl" else "torch.distributed.gather over gloo (rehearsal: stripes staged through host memory)"
-        paths = {"torch": {"ms_per_step": round(torch_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / torch_elapsed / 1e6, 1), "transport": torch_transport, "per_rank": spread(torch_kernels) if in_flight == 1 else None}}
-
-        # -- the module's own renderers, one rank per process: each form under a watchdog, validated against the torch form's frame --
-        results = {"torch": (torch_elapsed, torch_kernels, torch_member0, torch_transport, {})}  # form -> (elapsed, per-rank kernel ms, rank 0's stats, transport text, extra keys of the line)
-        state = {"chosen": "torch"}
-
-        def line_for(form):
-            form_elapsed, form_kernels, form_member0, form_transport, form_extras = results[form]
-            more = dict(form_extras, paths=paths, value_from=form, per_rank=spread(form_kernels) if in_flight == 1 else None)
-            if "rccl" not in more and args.backend == "nccl":
-                more["rccl"] = {"ranks": world, "devices": None, "transport": form_transport, "source": "torch.distributed's process group (the module's own communicator was not used)"}
-            return build_line(form, form_elapsed, form_kernels, form_member0, f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {form_transport}", more)
-
-        def guarded(form, deadline, body):
-            """body() under a watchdog: a form that does not come back (a collective that never completes cannot be
-            cancelled) costs the run nothing but that form — rank 0 prints the best line so far and every process ends."""
-            finished = threading.Event()
-
-            def watchdog():
-                if finished.wait(deadline):
-                    return
-                paths[form] = {"status": f"hung: no result within {deadline:.0f} s; the processes were ended by the benchmark's watchdog"}
-                if rank == 0:
-                    print(json.dumps(line_for(state["chosen"])), flush=True)
-                sys.stdout.flush()
-                os._exit(0)
-
-            threading.Thread(target=watchdog, daemon=True).start()
-            try:
-                return body()
-            finally:
-                finished.set()
-
-        def adopt(form):  # a drop-in form always outranks the torch form; among drop-in forms the faster one is `value`
-            if state["chosen"] == "torch" or results[form][0] < results[state["chosen"]][0]:
-                state["chosen"] = form
-
-        def measure_drop_in(form, form_tracer, back_buffer, transport_text, rccl_source):
-            """Validate (the very frame the torch form delivered), settle, time; fills paths[form] and results[form]."""
-            render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME
-            phase_samples: list[dict] = []
-
-            def form_step():  # collective and blocking: rank 0 returns with the frame in its back buffer
-                if os.environ.get("RT_BENCH_TEST_HANG") == form or os.environ.get("RT_BENCH_TEST_HANG") == "1":  # tests/test_bench_contract.py: the watchdog's rehearsal
-                    time.sleep(3600)
-                return form_tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
-
-            form_step()
-            same = True
-            if rank == 0:
-                same = bool(np.array_equal(np.asarray(back_buffer).view(np.int32), host_frame.numpy()))
-            if not distributed.all_agree(same, vote_device):
-                paths[form] = {"status": "frame differs from the torch form's frame: not used"}
-                return
-
-            def measured_step():
-                s = form_step()
-                phase_samples.append(form_tracer.phases())
-                return s
-
-            settle(own_share)  # (bringing a form up leaves the GPU idle for a moment: clocks up again first)
-            form_elapsed, form_kernels = timed(measured_step, lambda s: s["render_ms"] if form != "shared_frame" else form_tracer.member_stats(rank)["render_ms"])
-            phase_samples[:] = phase_samples[-args.steps :]
-            infos = [None] * world
-            dist.all_gather_object(infos, form_tracer.comm_info())
-            phases = mean_phases(phase_samples)
-            form_extras = {
-                "drop_in_breakdown": dict({"kernel_ms": round(form_kernels[0], 4), "wall_ms": round(form_elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases}),
-                "rccl": {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": rccl_source},
-            }
-            paths[form] = {"status": "ok", "ms_per_step": round(form_elapsed / args.steps * 1e3, 4), "value": round(samples_total * args.steps / form_elapsed / 1e6, 1), "per_rank": spread(form_kernels)}
-            results[form] = (form_elapsed, form_kernels, form_tracer.member_stats(0), transport_text, form_extras)  # (member 0 = rank 0's share: the launch the roofline prices)
-            adopt(form)
-
-        deadline = args.library_deadline_s or (120.0 + 50.0 * torch_form_seconds)
-        log = lambda message: print(message, file=sys.stderr, flush=True)  # noqa: E731
-
-        # -- form 2: rt_hip_join_frame_group — every rank's kernel stores its stripes straight into ONE shared back buffer;
-        #    no RCCL in the data path (so it also runs in the gloo rehearsal, where the ranks share a device) --
-        if args.gather == "library":
-
-            def shared_form():
-                names = [None]
-                if rank == 0:
-                    names[0] = f"rt_hip_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFFFF:08x}"
-                dist.broadcast_object_list(names, src=0)
-                frame_path = f"/dev/shm/{names[0]}_frame"
-                shared = None
-                try:
-                    created = True
-                    if rank == 0:  # the "caller's back buffer": a shared mapping every rank process maps
-                        try:
-                            with open(frame_path, "wb") as f:
-                                f.truncate(args.height * args.width * 4)
-                            shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
-                            shared[:] = 0  # rt clears its back buffer before every render (src/main.cpp:318): the pages exist, first touched by rank 0
-                        except OSError as e:
-                            log(f"rank 0: the shared frame {frame_path} could not be made: {e}")
-                            created = False
-                    if not distributed.all_agree(created, vote_device):  # (also the barrier: the file exists before anybody maps it)
-                        paths["shared_frame"] = {"status": f"not available: {frame_path} could not be created"}
-                        return
-                    group_tracer, reason = distributed.negotiate_rank_renderer(
-                        create=lambda: rt_amd.HipRayTracer(device=device),
-                        join=lambda t, unique: t.join_frame_group(rank, world, f"/{names[0]}_group", timeout_ms=int(min(deadline, 120.0) * 1e3)),
-                        make_id=lambda: bytes(128),  # (nothing to hand out: the group's name is all the ranks need)
-                        vote_device=vote_device,
-                        log=log,
-                    )
-                    if group_tracer is None:
-                        paths["shared_frame"] = {"status": f"not available: {reason}"}
-                        return
-                    tracers.append(group_tracer)
-                    if shared is None:
-                        shared = np.memmap(frame_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
-                    measure_drop_in("shared_frame", group_tracer, shared,
-                                    "inside librt_hip.so: rt_hip_create + rt_hip_join_frame_group; every rank's kernel stores its stripes straight into ONE shared, page-locked back buffer over its own PCIe link; no data-path collective (two shared-memory counters per frame); torch.distributed only hands out the name, votes and keeps time",
-                                    "no communicator: rt_hip_join_frame_group's control block in POSIX shared memory (this transport does not use RCCL)")
-                except rt_amd.RtHipError as e:  # a frame group reports a broken frame on every rank alike
-                    paths["shared_frame"] = {"status": f"failed: {e}"}
-                finally:
-                    dist.barrier()
-                    if rank == 0:
-                        try:
-                            os.unlink(frame_path)
-                        except OSError:
-                            pass
-
-            guarded("shared_frame", deadline, shared_form)
-
-        # -- form 3: rt_hip_join_ranks — ncclCommInitRank, one ncclGather to rank 0, assemble into rank 0's page-locked back buffer --
-        if args.gather == "library" and args.backend == "nccl":
-
-            def library_form():
-                rank_tracer, reason = distributed.negotiate_rank_renderer(
-                    create=lambda: rt_amd.HipRayTracer(device=device),
-                    join=lambda t, unique: t.join_ranks(rank, world, unique, timeout_ms=int(min(deadline, 120.0) * 1e3)),
-                    make_id=rt_amd.unique_id,
-                    vote_device=vote_device,
-                    log=log,
-                )
-                if rank_tracer is None:
-                    paths["library"] = {"status": f"not available: {reason}"}
-                    return
-                tracers.append(rank_tracer)
-                back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
-                measure_drop_in("library", rank_tracer, back_buffer,
-                                "inside librt_hip.so: rt_hip_create + rt_hip_join_ranks (ncclCommInitRank) + one ncclGather to rank 0; torch.distributed only hands out the id, votes and keeps time",
-                                "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on every rank's communicator")
-
-            paths["library"] = {"status": "not attempted"}
-            guarded("library", deadline, library_form)
-        elif args.gather == "library":
-            paths["library"] = {"status": "not attempted: --backend gloo rehearses the torch and the shared-frame forms only"}
-        chosen = state["chosen"]
-        elapsed, per_rank_kernel_ms, member0, transport, chosen_extras = results[chosen]
-        stats = member0
-        extras.update(chosen_extras)
-        extras["paths"] = paths
-        extras["value_from"] = chosen
-        extras["per_rank"] = spread(per_rank_kernel_ms) if in_flight == 1 else None
-        if "rccl" not in extras and args.backend == "nccl":
-            extras["rccl"] = {"ranks": world, "devices": None, "transport": transport, "source": "torch.distributed's process group (the module's own communicator was not used)"}
-        parallelism = f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {transport}"
-
-    if rank == 0:
-        if single_process:
-            line = build_line("single", elapsed, per_rank_kernel_ms, member0, parallelism, extras)
-        else:
-            line = build_line(extras["value_from"], elapsed, per_rank_kernel_ms, member0, parallelism, extras)
-        if plug_in_call:
-            line["plug_in_call"] = plug_in_call
-        if kernel_only:
-            line["kernel_only"] = kernel_only
-        if n_gpus == 1 and single_process and args.cpu_baseline_seconds > 0:
-            line["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.cpu_baseline_seconds)
-        print(json.dumps(line), flush=True)
-
-    if not single_process:
-        dist.barrier()
-        dist.destroy_process_group()
+    line = build_line("single", elapsed, per_rank_kernel_ms, member0, parallelism, extras)
+    if plug_in_call:
+        line["plug_in_call"] = plug_in_call
+    if kernel_only:
+        line["kernel_only"] = kernel_only
+    if n_gpus == 1 and args.cpu_baseline_seconds > 0:
+        line["cpu_baseline"] = cpu_baseline(args.scene, args.width, args.height, args.cpu_baseline_seconds)
+    print(json.dumps(line), flush=True)
     for t in tracers:
         t.close()
+
+
+# ---- one process per GPU (torchrun) ----------------------------------------------------------------------------------------------
+
+FORMS = ("library", "shared_frame", "torch")
+FORM_TEXT = {
+    "library": "inside librt_hip.so: rt_hip_create + rt_hip_join_ranks (ncclCommInitRank) + one ncclGather over xGMI to rank 0, assembled into rank 0's frame; torch.distributed (gloo) only hands out the id, votes and keeps time",
+    "shared_frame": "inside librt_hip.so: rt_hip_create + rt_hip_join_frame_group; every rank's kernel stores its stripes straight into ONE shared, page-locked back buffer over its own PCIe link; no data-path collective (two shared-memory counters per frame); torch.distributed (gloo) only hands out the name, votes and keeps time",
+}
+
+
+def local_rows_of(height: int, rank: int, world: int, stripe_rows: int = 8) -> int:
+    """rt_hip_local_rows in plain Python (the torchrun-launched process does not load librt_hip.so)."""
+    stripes = (height + stripe_rows - 1) // stripe_rows
+    return sum(min(stripe_rows, height - b * stripe_rows) for b in range(rank, stripes, world))
+
+
+def form_main(args) -> None:
+    """The child process of ONE form on one rank: the only process of this rank that touches the GPU while it lives."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import rt_amd
+    from rt_amd import capi, distributed
+
+    form = args.form
+    rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    result_path = os.environ["RT_BENCH_FORM_RESULT"]
+    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import datetime
+
+    # the control plane (votes, ids, barriers, clocks) is gloo; only the torch form's own data path wants RCCL from torch
+    data_backend = args.backend if form == "torch" else "gloo"
+    if data_backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", device), timeout=datetime.timedelta(seconds=120))  # "nccl" is RCCL on ROCm
+    else:
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+    vote_device = "cuda" if data_backend == "nccl" else "cpu"
+    log = lambda message: print(f"[{form}] {message}", file=sys.stderr, flush=True)  # noqa: E731
+
+    scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
+    pod = scene.describe(args.width, args.height)
+    flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
+    if args.fast:
+        flags |= capi.RT_HIP_FLAG_FAST
+    samples_total = args.width * args.height * args.spp
+    result: dict = {"form": form, "status": "failed: the form's process ended without a verdict"}
+
+    def finish(status: str, **more) -> None:
+        result.clear()
+        result.update({"form": form, "status": status}, **more)
+        if rank == 0:
+            with open(result_path + ".tmp", "w") as f:
+                json.dump(result, f)
+            os.replace(result_path + ".tmp", result_path)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn, kernel_ms_of):
+        """W warm-up steps, then exactly K steps between two fences; max over ranks; every rank's mean kernel time."""
+        for _ in range(args.warmup):
+            step_fn()
+        fence()
+        kernel_sum = 0.0
+        t_begin = time.perf_counter()
+        for _ in range(args.steps):
+            used = step_fn()
+            kernel_sum += kernel_ms_of(used)
+        fence()
+        local = time.perf_counter() - t_begin
+        t = torch.tensor([local], dtype=torch.float64, device=vote_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        kernels = [None] * world
+        dist.all_gather_object(kernels, kernel_sum / args.steps)
+        return float(t.item()), [float(k) for k in kernels]
+
+    def settle_collectively(step_fn):
+        """Untimed steps that bring the clocks up from idle: the SAME number on every rank (the step is collective)."""
+        t0 = time.perf_counter()
+        step_fn()
+        counts = [max(4, int(args.settle_ms * 1e-3 / max(time.perf_counter() - t0, 1e-5)))] if rank == 0 else [None]
+        dist.broadcast_object_list(counts, src=0)
+        for _ in range(min(int(counts[0]), 400)):
+            step_fn()
+
+    # what every form's first frame is held against: the frame rank 0 renders ALONE on its GPU (random streams are keyed by
+    # the global pixel index: the frame does not depend on how it is split)
+    reference = None
+    if rank == 0:
+        with rt_amd.HipRayTracer(device=device) as alone:
+            reference = alone.render(pod, args.width, args.height, seed=args.seed, flags=flags, stats=False)[0].copy()
+
+    tracers = []
+    shared_path = None
+    try:
+        if form == "torch":
+            in_flight = max(1, args.frames_in_flight) if args.gather == "torch" else 1
+            tracers = [rt_amd.HipRayTracer(device=device) for _ in range(in_flight)]
+            for t in tracers:
+                t.upload(pod)
+            frame_maker = distributed.DistributedFrame(tracers, args.width, args.height)
+            host_frame = torch.empty((args.height, args.width), dtype=torch.int32).pin_memory() if rank == 0 else None
+
+            def torch_step():
+                frame = frame_maker.render(seed=args.seed, flags=flags)
+                if frame is not None:
+                    host_frame.copy_(frame, non_blocking=True)  # the frame lands in host memory, as render() must deliver it
+                if in_flight == 1:
+                    torch.cuda.synchronize()  # one frame at a time: what a blocking caller gets
+                return tracers[(frame_maker.frames - 1) % in_flight]
+
+            torch_step()
+            torch.cuda.synchronize()
+            same = True if rank != 0 else bool(np.array_equal(host_frame.numpy().view(np.uint32), reference))
+            if not distributed.all_agree(same, vote_device):
+                return finish("frame differs from the frame rank 0 renders alone: not used")
+            settle_collectively(torch_step)
+            elapsed, kernels = timed(torch_step, (lambda used: used.stats()["render_ms"]) if in_flight == 1 else (lambda used: float("nan")))
+            torch.cuda.synchronize()
+            transport = "torch.distributed.gather (backend nccl = RCCL)" if args.backend == "nccl" else "torch.distributed.gather over gloo (rehearsal: stripes staged through host memory)"
+            return finish("ok", elapsed=elapsed, kernels=kernels, member0=tracers[(args.steps - 1) % in_flight].stats(), transport_text=transport, extras={}, frames_in_flight=in_flight)
+
+        back_buffer = None
+        if form == "shared_frame":
+            names = [f"rt_hip_bench_{os.getpid()}_{int(time.time() * 1e6) & 0xFFFFFFFF:08x}"] if rank == 0 else [None]
+            dist.broadcast_object_list(names, src=0)
+            shared_path = f"/dev/shm/{names[0]}_frame"
+            created = True
+            if rank == 0:  # the "caller's back buffer": a shared mapping every rank process maps
+                try:
+                    with open(shared_path, "wb") as f:
+                        f.truncate(args.height * args.width * 4)
+                    back_buffer = np.memmap(shared_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+                    back_buffer[:] = 0  # rt clears its back buffer before every render (src/main.cpp:318): the pages exist, first touched by rank 0
+                except OSError as e:
+                    log(f"rank 0: the shared frame {shared_path} could not be made: {e}")
+                    created = False
+            if not distributed.all_agree(created, vote_device):  # (also the barrier: the file exists before anybody maps it)
+                return finish(f"not available: {shared_path} could not be created")
+            tracer, reason = distributed.negotiate_rank_renderer(
+                create=lambda: rt_amd.HipRayTracer(device=device),
+                join=lambda t, unique: t.join_frame_group(rank, world, f"/{names[0]}_group", timeout_ms=60000),
+                make_id=lambda: bytes(128),  # (nothing to hand out: the group's name is all the ranks need)
+                vote_device=vote_device,
+                log=log,
+            )
+            if tracer is None:
+                return finish(f"not available: {reason}")
+            tracers.append(tracer)
+            if back_buffer is None:
+                back_buffer = np.memmap(shared_path, dtype=np.uint32, mode="r+", shape=(args.height, args.width))
+            render_flags = flags | capi.RT_HIP_FLAG_PERSISTENT_FRAME  # (implied by the group: the shared buffer is page-locked by design)
+            rccl_source = "no communicator: rt_hip_join_frame_group's control block in POSIX shared memory (this transport does not use RCCL)"
+        else:  # library
+            if args.backend != "nccl":
+                return finish("not attempted: --backend gloo rehearses the torch and the shared-frame forms only")
+            tracer, reason = distributed.negotiate_rank_renderer(
+                create=lambda: rt_amd.HipRayTracer(device=device),
+                join=lambda t, unique: t.join_ranks(rank, world, unique, timeout_ms=60000),
+                make_id=rt_amd.unique_id,
+                vote_device=vote_device,
+                log=log,
+            )
+            if tracer is None:
+                return finish(f"not available: {reason}")
+            tracers.append(tracer)
+            back_buffer = np.zeros((args.height, args.width), dtype=np.uint32) if rank == 0 else None
+            render_flags = flags  # the default delivery: the module's own page-locked frame, carried into the pageable back buffer
+            rccl_source = "ncclCommCount / ncclCommUserRank / ncclCommCuDevice on every rank's communicator"
+
+        phase_samples: list[dict] = []
+
+        def form_step():  # collective and blocking: rank 0 returns with the frame in its back buffer
+            if os.environ.get("RT_BENCH_TEST_HANG") in (form, "1"):  # tests/test_bench_contract.py: the deadline's rehearsal
+                time.sleep(3600)
+            return tracer.render(pod, args.width, args.height, seed=args.seed, flags=render_flags, out=back_buffer)[2]
+
+        form_step()
+        same = True if rank != 0 else bool(np.array_equal(np.asarray(back_buffer), reference))
+        if not distributed.all_agree(same, vote_device):
+            return finish("frame differs from the frame rank 0 renders alone: not used")
+
+        def measured_step():
+            s = form_step()
+            phase_samples.append(tracer.phases())
+            return s
+
+        settle_collectively(form_step)
+        elapsed, kernels = timed(measured_step, lambda s: s["render_ms"] if form != "shared_frame" else tracer.member_stats(rank)["render_ms"])
+        phase_samples[:] = phase_samples[-args.steps :]
+        infos = [None] * world
+        dist.all_gather_object(infos, tracer.comm_info())
+        phases = mean_phases(phase_samples)
+        extras = {
+            "drop_in_breakdown": dict({"kernel_ms": round(kernels[0], 4), "wall_ms": round(elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases}),
+            "rccl": {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": rccl_source},
+        }
+        return finish("ok", elapsed=elapsed, kernels=kernels, member0=tracer.member_stats(0), transport_text=FORM_TEXT[form], extras=extras, frames_in_flight=1)  # (member 0 = rank 0's share: the launch the roofline prices)
+    except rt_amd.RtHipError as e:  # a collective renderer reports a broken frame on every rank alike
+        finish(f"failed: {e}")
+    finally:
+        for t in tracers:
+            t.close()
+        try:
+            dist.barrier()
+        except Exception:  # noqa: BLE001 - a rank that died earlier: nothing left to wait for
+            pass
+        if shared_path and rank == 0:
+            try:
+                os.unlink(shared_path)
+            except OSError:
+                pass
+        dist.destroy_process_group()
+
+
+def forms_parent_main(args) -> None:
+    """What torchrun starts on every rank: never touches a GPU.  Runs the forms one after the other, each as a child process
+    per rank (own rendezvous port), kills a child that does not come back, and rank 0 prints the line."""
+    import socket
+
+    import torch.distributed as dist
+
+    import rt_amd
+
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")  # CPU only: ports, verdicts
+    n_gpus = args.gpus
+    scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
+    pod = scene.describe(args.width, args.height)  # (host library only)
+    samples_total = args.width * args.height * args.spp
+    build_line = make_build_line(args, pod, n_gpus, False)
+    deadline = args.library_deadline_s or 180.0
+    forms = ["torch"] if args.gather == "torch" else list(FORMS)
+
+    paths: dict = {}
+    results: dict = {}
+    any_hung = False
+    for form in forms:
+        ports = [None]
+        if rank == 0:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                ports[0] = s.getsockname()[1]
+        dist.broadcast_object_list(ports, src=0)
+        result_path = f"/tmp/rt_bench_{os.getpid()}_{form}.json"
+        env = dict(os.environ, MASTER_PORT=str(ports[0]), RT_BENCH_FORM_RESULT=result_path)
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--form", form], env=env)
+        hung = False
+        try:
+            rc = child.wait(timeout=deadline)
+        except subprocess.TimeoutExpired:
+            child.kill()  # this very child, by pid
+            child.wait()
+            rc, hung = -9, True
+        verdicts = [None] * world
+        dist.all_gather_object(verdicts, (rc, hung))
+        hung_anywhere = any(h for _, h in verdicts)
+        any_hung = any_hung or hung_anywhere
+        if rank == 0:
+            outcome = None
+            try:
+                with open(result_path) as f:
+                    outcome = json.load(f)
+                os.unlink(result_path)
+            except (OSError, ValueError):
+                pass
+            if hung_anywhere:
+                paths[form] = {"status": f"hung: no result within {deadline:.0f} s on rank(s) {[r for r, (_, h) in enumerate(verdicts) if h]}; the form's processes were killed"}
+                for leftover in [p for p in os.listdir("/dev/shm") if p.startswith("rt_hip_bench_")]:  # what a killed form may leave behind
+                    try:
+                        os.unlink(os.path.join("/dev/shm", leftover))
+                    except OSError:
+                        pass
+            elif outcome is None or any(code != 0 for code, _ in verdicts):
+                paths[form] = {"status": f"failed: exit codes {[code for code, _ in verdicts]}" + (f"; {outcome['status']}" if outcome else "")}
+            elif outcome["status"] != "ok":
+                paths[form] = {"status": outcome["status"]}
+            else:
+                results[form] = outcome
+                paths[form] = {"status": "ok", "ms_per_step": round(outcome["elapsed"] / args.steps * 1e3, 4), "value": round(samples_total * args.steps / outcome["elapsed"] / 1e6, 1),
+                               "per_rank": spread(outcome["kernels"]) if outcome.get("frames_in_flight", 1) == 1 else None, "transport": outcome["transport_text"] if form == "torch" else outcome["extras"]["rccl"]["transport"]}
+
+    exit_code = 3 if any_hung else 0
+    if rank == 0:
+        # `value` is the form north_star names — the single RCCL gather inside the module — whenever it came up; the others are
+        # side keys (`paths`).  Only if it did not: the next form that did, and `paths.library.status` says why.
+        chosen = next((f for f in forms if f in results), None)
+        if chosen is None:
+            print(json.dumps({"metric": f"Mrays/s (W*H*spp per second) and wall-clock, {args.width}x{args.height}x{args.spp}spp scenes/{args.scene}.toml", "value": None, "unit": "Mrays/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+                              "status": "no form produced a result", "paths": paths}), flush=True)
+            exit_code = exit_code or 4
+        else:
+            outcome = results[chosen]
+            in_flight = outcome.get("frames_in_flight", 1)
+            more = dict(outcome["extras"], paths=paths, value_from=chosen, per_rank=spread(outcome["kernels"]) if in_flight == 1 else None)
+            if "rccl" not in more:
+                more["rccl"] = {"ranks": world, "devices": None, "transport": outcome["transport_text"], "source": "torch.distributed's process group (the module's own communicator was not used)"}
+            line = build_line(chosen, outcome["elapsed"], outcome["kernels"], outcome["member0"], f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {outcome['transport_text']}", more)
+            line["config"]["frames_in_flight"] = in_flight
+            print(json.dumps(line), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(exit_code)
 
 
 if __name__ == "__main__":

@@ -220,8 +220,9 @@ def test_every_sphere_and_plane_count_of_the_scalar_register_kernel(tracer, n_sp
         n /= np.linalg.norm(n)
         planes.append((*n, rng.uniform(2.0, 6.0), rng.integers(0, n_mat)))
     width, height, spp, bounces = 96, 54, int(rng.integers(3, 40)), int(rng.integers(2, 9))
-    camera = rt_amd.Scene.parse("").set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+    camera = rt_amd.Scene.parse("").set_camera((0.0, 1.0, 3.0), (0.0, -0.2, -1.0))
     ivp = camera.describe(width, height).inverse_view_projection[:]
+    assert ivp[12] == 0.0 and ivp[13] == 0.0  # w constant over the frame: what the scalar-register kernel asks of the camera
     pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
     in_registers = n_spheres >= 1 and n_planes <= 3 and n_spheres + n_planes <= 8
     for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, capi.RT_HIP_FLAG_FORCE_WHOLE_CHUNKS, SM):

@@ -6,13 +6,6 @@ set -o pipefail
 mkdir -p gpurun_out/r04
 cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
-echo "== pageable diag (round-3 library) =="
-RT_HIP_LIBRARY=$PWD/rt_amd/lib/librt_hip_r3.so AMD_LOG_LEVEL=4 AMD_LOG_MASK=1792 timeout -k 10 300 python tools/gpu_pageable_diag.py > gpurun_out/r04/pageable_diag_stdout.txt 2> /tmp/pageable_diag_amdlog.txt; echo "rc=$?"
-grep -E "Pinned resource|Staging resource|staging D2H|staging H2D|Unpinned|pinned" /tmp/pageable_diag_amdlog.txt | sed -E 's/^[^]]*\] //; s/0x[0-9a-f]+/ADDR/g' | sort | uniq -c | sort -rn | head -30 > gpurun_out/r04/pageable_diag_copy_paths.txt
-head -12 gpurun_out/r04/pageable_diag_copy_paths.txt
-grep -E "Pinned|pinned|Staging|staging" /tmp/pageable_diag_amdlog.txt | head -120 > gpurun_out/r04/pageable_diag_copy_lines.txt
-head -c 200000 /tmp/pageable_diag_amdlog.txt > gpurun_out/r04/pageable_diag_amdlog_head.txt
-tail -10 gpurun_out/r04/pageable_diag_stdout.txt
 echo "== pytest -m gpu (once) =="
 timeout -k 10 1000 python -m pytest tests -m gpu -q -x --timeout 400 -p no:cacheprovider > gpurun_out/r04/pytest_gpu.txt 2>&1; rc=$?; tail -30 gpurun_out/r04/pytest_gpu.txt
 [ $rc -ne 0 ] && exit $rc
