@@ -433,10 +433,20 @@ def form_main(args) -> None:
     form = args.form
     rank, world, local_rank = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
     result_path = os.environ["RT_BENCH_FORM_RESULT"]
-    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(device)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     import datetime
+
+    if os.environ.get("RT_BENCH_DRY_RUN"):  # tests/test_bench_contract.py on a box without a GPU: the processes, ports and verdicts only
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+        everybody = distributed.all_agree(True)
+        if rank == 0:
+            with open(result_path, "w") as f:
+                json.dump({"form": form, "status": f"dry run: {world} rank(s) met on port {os.environ['MASTER_PORT']}" if everybody else "dry run: no agreement"}, f)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    device = local_rank if args.backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(device)
 
     # the control plane (votes, ids, barriers, clocks) is gloo; only the torch form's own data path wants RCCL from torch
     data_backend = args.backend if form == "torch" else "gloo"
@@ -656,7 +666,9 @@ def forms_parent_main(args) -> None:
                 ports[0] = s.getsockname()[1]
         dist.broadcast_object_list(ports, src=0)
         result_path = f"/tmp/rt_bench_{os.getpid()}_{form}.json"
-        env = dict(os.environ, MASTER_PORT=str(ports[0]), RT_BENCH_FORM_RESULT=result_path)
+        # the children rendezvous among themselves on a port of their own: rank 0's child hosts that store (under torchrun the
+        # workers are told to use the launcher's store — which listens on the launcher's port only)
+        env = dict(os.environ, MASTER_PORT=str(ports[0]), RT_BENCH_FORM_RESULT=result_path, TORCHELASTIC_USE_AGENT_STORE="False")
         child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--form", form], env=env)
         hung = False
         try:

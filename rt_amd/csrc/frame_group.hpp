@@ -17,6 +17,7 @@
 
 #include <fcntl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
@@ -65,6 +66,7 @@ namespace rt_hip
 	{
 		std::atomic<uint32_t> magic; // stored last by the creator
 		uint32_t world;
+		int32_t creator_pid; // rank 0's process: a block whose creator is gone (or whose join is over) is a leftover, not this group's
 		alignas(64) std::atomic<uint64_t> joined;
 		alignas(64) std::atomic<uint64_t> entered;	 // + 1 per rank per frame: everybody is inside rt_hip_render
 		alignas(64) std::atomic<uint64_t> nonce_set; // + 1 per rank per buffer check: rank 0's mark is in the buffer
@@ -124,6 +126,13 @@ namespace rt_hip
 			if (rank == 0)
 			{
 				fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+				if (fd < 0 && errno == EEXIST && is_leftover(name))
+				{
+					// a block of that name from a run that crashed (its creator is gone) or is over (its join completed and the
+					// name should have been removed): not this group's — replaced
+					(void)shm_unlink(name);
+					fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+				}
 				if (fd < 0)
 					return fail("shm_open(%s, O_CREAT | O_EXCL) failed: %s", name, std::strerror(errno));
 				name_ = name;
@@ -142,8 +151,10 @@ namespace rt_hip
 					if (fd >= 0)
 					{
 						struct stat st;
-						if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= sizeof(frame_group_block))
-							break; // created AND sized
+						// created AND sized — and not a leftover of an earlier run under the same name (rank 0 replaces those: wait
+						// for the replacement instead of joining a block whose counters are already at their targets)
+						if (fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= sizeof(frame_group_block) && !is_leftover_fd(fd))
+							break;
 						(void)close(fd);
 						fd = -1;
 					}
@@ -163,6 +174,7 @@ namespace rt_hip
 			if (rank == 0)
 			{
 				block->world = world;
+				block->creator_pid = static_cast<int32_t>(getpid());
 				block->magic.store(frame_group_magic, std::memory_order_release);
 			}
 			else
@@ -183,6 +195,14 @@ namespace rt_hip
 			const outcome all_here = wait_for(block->joined, world, "to join", true);
 			deadline_ms = frame_deadline;
 			unlink_name(); // (on every outcome: a group that did not form leaves nothing behind either)
+			if (all_here == outcome::ok)
+			{
+				// Can this process see the other ranks' process ids at all (one pid namespace)?  Everybody has just arrived, so
+				// everybody is alive: if a rank looks dead NOW, pids mean nothing here and the waits below rely on the deadline alone.
+				for (uint32_t r = 0; r < world; r++)
+					if (r != rank && !process_exists(block->ranks[r].pid))
+						pids_visible_ = false;
+			}
 			return all_here;
 		}
 
@@ -266,6 +286,50 @@ namespace rt_hip
 
 	  private:
 		std::string name_; // rank 0: the object's name while it still exists
+		bool pids_visible_ = true; // the ranks' process ids can be probed from this process (checked when the group forms)
+
+		// alive, as far as this process can tell: the pid exists and is not a zombie (a rank that died is a zombie until its
+		// launcher reaps it, and kill(pid, 0) still succeeds on those)
+		static bool process_exists(int32_t pid)
+		{
+			if (pid <= 0 || !(kill(static_cast<pid_t>(pid), 0) == 0 || errno == EPERM))
+				return false;
+			char path[64], text[512];
+			std::snprintf(path, sizeof(path), "/proc/%d/stat", static_cast<int>(pid));
+			const int fd = open(path, O_RDONLY | O_CLOEXEC);
+			if (fd < 0)
+				return true; // (no /proc to ask: the pid exists, that is all that can be said)
+			const ssize_t n = read(fd, text, sizeof(text) - 1);
+			(void)close(fd);
+			if (n <= 0)
+				return true;
+			text[n] = '\0';
+			const char* const after_name = std::strrchr(text, ')'); // "pid (comm) S ...": comm may contain anything but ends at the LAST ')'
+			return !(after_name && after_name[1] == ' ' && (after_name[2] == 'Z' || after_name[2] == 'X'));
+		}
+		// A block found under the group's name that cannot be THIS group's: initialised, and either its creator is gone or
+		// everybody of ITS world had joined (a live group removes its name at that moment) or it was broken.
+		static bool is_leftover_fd(int fd)
+		{
+			void* const mapping = mmap(nullptr, sizeof(frame_group_block), PROT_READ, MAP_SHARED, fd, 0);
+			if (mapping == MAP_FAILED)
+				return false;
+			const frame_group_block* const found = static_cast<const frame_group_block*>(mapping);
+			const bool initialised = found->magic.load(std::memory_order_acquire) == frame_group_magic;
+			const bool leftover = initialised && (!process_exists(found->creator_pid) || found->joined.load(std::memory_order_acquire) >= found->world || found->broken.load(std::memory_order_acquire) != 0);
+			(void)munmap(mapping, sizeof(frame_group_block));
+			return leftover;
+		}
+		static bool is_leftover(const char* name)
+		{
+			const int fd = shm_open(name, O_RDWR, 0600);
+			if (fd < 0)
+				return false;
+			struct stat st;
+			const bool leftover = fstat(fd, &st) == 0 && static_cast<size_t>(st.st_size) >= sizeof(frame_group_block) && is_leftover_fd(fd);
+			(void)close(fd);
+			return leftover;
+		}
 
 		void unlink_name()
 		{
@@ -344,7 +408,18 @@ namespace rt_hip
 					if (spins < 200000)
 						(void)sched_yield();
 					else
+					{
+						// the slow path: somebody is late by milliseconds.  A rank whose PROCESS is gone (an HSA abort, a kill) will
+						// never arrive: say so now, not at the deadline
+						if (pids_visible_ && (spins & 63u) == 0)
+							for (uint32_t r = 0; r < world; r++)
+								if (r != rank && block->ranks[r].pid > 0 && !process_exists(block->ranks[r].pid))
+								{
+									break_group("rank %u's process (pid %d) is gone; rank %u was waiting for the other ranks %s", r, block->ranks[r].pid, rank, what);
+									return broken();
+								}
 						nap(50);
+					}
 				}
 			}
 		}

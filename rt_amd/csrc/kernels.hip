@@ -304,19 +304,96 @@ namespace rt_hip
 			return (static_cast<unsigned long long>(hi) << 32) | lo;
 		}
 
-		// a chunk sum on its way between waves: 16 bytes per item, written and read with agent-scope accesses only
-		// (global_store / global_load ... sc1: through to memory, past this CU's L1 and this XCD's L2)
+		// A value (a chunk's sum, or one sample's) on its way between waves: 16 bytes per slot, ONE store and ONE load, both
+		// past this CU's L1 and this XCD's L2 (... sc1: the XCDs' L2s are not coherent with one another).
+		//   Round 3 wrote a slot as an 8-byte and a 4-byte agent-scope atomic store and read it back the same way: two memory
+		//   requests each way per sample, tallied by the counters at 32 bytes apiece (config 5: WRITE_SIZE 8.9 GB for 2.1 GB of
+		//   payload).  hipcc has no 16-byte atomic, so the single dwordx4 access is written out
+		//   (RT_HIP_SPLIT_PUBLISH=1 builds the old form, for the A/B).
+		// THE HAND-OVER PROTOCOL (publish -> count the arrival -> the last arrival reads), as the hardware executes it:
+		//   1. the producer's stores are write-through (sc1): when `s_waitcnt vmcnt(0)` lets the wave go on, they have been
+		//      acknowledged by the memory side (gfx950 counts stores in vmcnt and acknowledges a write-through store when it
+		//      has left the L2 for the fabric);
+		//   2. the arrival is an agent-scope atomic add, executed at the memory side, issued after (1) in program order;
+		//   3. the consumer's loads are issued after the atomic's RETURN VALUE has come back (they depend on the branch on
+		//      it) and bypass the non-coherent caches (sc1): they observe memory as of a moment after every producer's (1).
+		// That is an argument from the gfx950 ISA, not from the HIP memory model: in the model's terms the
+		// arrival would be a release (buffer_wbl2 sc1 + s_waitcnt in front of the atomic) and the last arrival an acquire
+		// (buffer_inv sc1 behind it).  RT_HIP_MODEL_ORDERING=1 builds exactly that; measured, it costs the streamed kernel
+		// its scene — buffer_inv sc1 drops the XCD's L2 copy of the sphere table once per finished pixel
+		// (profiles/r04/arrival_ordering_ab.txt) — so the ISA-level form stays, and this file refuses to be compiled for
+		// anything but gfx950, where the argument was made and the suite's parity tests exercise it.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels.hip: the cross-wave hand-over of the rolling kernels relies on gfx950's store acknowledgement and sc1 semantics"
+#endif
+		typedef float v4f __attribute__((ext_vector_type(4)));
+
 		__device__ __forceinline__ void publish_sum(unsigned long long* slot, vec3 sum)
 		{
+#ifdef RT_HIP_SPLIT_PUBLISH
 			const unsigned long long xy = (static_cast<unsigned long long>(__float_as_uint(sum.y)) << 32) | __float_as_uint(sum.x);
 			__hip_atomic_store(slot, xy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			__hip_atomic_store(reinterpret_cast<uint32_t*>(slot + 1), __float_as_uint(sum.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+			const v4f value = { sum.x, sum.y, sum.z, 0.0f };
+			asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(slot), "v"(value) : "memory");
+#endif
 		}
 		__device__ __forceinline__ vec3 read_sum(unsigned long long* slot)
 		{
+#ifdef RT_HIP_SPLIT_PUBLISH
 			const unsigned long long xy = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			const uint32_t z = __hip_atomic_load(reinterpret_cast<uint32_t*>(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 			return { __uint_as_float(static_cast<uint32_t>(xy)), __uint_as_float(static_cast<uint32_t>(xy >> 32)), __uint_as_float(z) };
+#else
+			v4f value;
+			asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(value) : "v"(slot) : "memory");
+			return { value.x, value.y, value.z };
+#endif
+		}
+		// eight consecutive slots, the loads in flight together
+		__device__ __forceinline__ void read_sums8(unsigned long long* first, vec3 (&out)[8])
+		{
+#ifdef RT_HIP_SPLIT_PUBLISH
+#pragma unroll
+			for (uint32_t k = 0; k < 8u; k++)
+				out[k] = read_sum(first + 2u * k);
+#else
+			v4f v0, v1, v2, v3, v4, v5, v6, v7;
+			asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
+						 "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+						 "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+						 "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+						 "global_load_dwordx4 %4, %8, off offset:64 sc1\n\t"
+						 "global_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+						 "global_load_dwordx4 %6, %8, off offset:96 sc1\n\t"
+						 "global_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+						 "s_waitcnt vmcnt(0)"
+						 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(v6), "=&v"(v7)
+						 : "v"(first)
+						 : "memory");
+			out[0] = { v0.x, v0.y, v0.z }, out[1] = { v1.x, v1.y, v1.z }, out[2] = { v2.x, v2.y, v2.z }, out[3] = { v3.x, v3.y, v3.z };
+			out[4] = { v4.x, v4.y, v4.z }, out[5] = { v5.x, v5.y, v5.z }, out[6] = { v6.x, v6.y, v6.z }, out[7] = { v7.x, v7.y, v7.z };
+#endif
+		}
+
+		// the arrival of an item at its pixel's counter, and what the lane that brings the LAST item does before it reads
+		__device__ __forceinline__ uint32_t count_arrival(uint32_t* counter)
+		{
+#ifdef RT_HIP_MODEL_ORDERING
+			return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#else
+			asm volatile("s_waitcnt vmcnt(0) ; what was published has left before the arrival is counted" ::: "memory");
+			return __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+		}
+		__device__ __forceinline__ void last_arrival()
+		{
+#ifdef RT_HIP_MODEL_ORDERING
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#else
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below the counter's answer)
+#endif
 		}
 
 		// HALF (small and resident kernels, short launches; see choose_queue): the unit of work is HALF a chunk, 8 samples.
@@ -340,7 +417,7 @@ namespace rt_hip
 																	  float* __restrict__ out_rgb,
 																	  device_counters* __restrict__ counters,
 																	  unsigned long long* item_sums, // [NS < 0] chunk sums in transit: 16 bytes per item
-																	  uint32_t* pixel_done)			 // [NS < 0] chunks arrived per pixel (0 between launches)
+																	  uint32_t* pixel_done)			 // [NS < 0] items arrived per pixel (zeroed in front of every launch)
 		{
 			extern __shared__ float4 lds[];
 			// [NS > 0] 8 geometry + 8 shading float4s, 8 metal flags | [NS == 0] all primitives; then the chunk slots
@@ -415,7 +492,22 @@ namespace rt_hip
 			//   free    - between items                       restart - has a sample to start (needs a primary ray)
 			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
 			enum : uint32_t { lane_free, lane_restart, lane_trace, lane_retired };
-			uint32_t mode = lane_free;
+#ifdef RT_HIP_MODE_REGISTER
+			uint32_t mode = lane_free; // (round 3's form, kept for the A/B: the mode as a number in a vector register)
+#define RT_HIP_IS(m) (mode == (m))
+#define RT_HIP_BECOME(m) (mode = (m))
+#else
+			// Round 4's one structural experiment ("fewer lane modes"): the mode is not a per-lane NUMBER that every
+			// use has to compare (a v_cmp per question, a v_cndmask / v_mov per change) but three lane MASKS — the compiler keeps
+			// a bool that lives across loop trips as a 64-bit scalar pair and combines such masks on the scalar unit, which has
+			// slots to spare here (0.40 scalar per vector instruction) while the vector unit is the one at its issue limit.
+			// free = none of the three.  Same transitions, same frames.
+			bool in_trace = false, in_restart = false, in_retired = false;
+			const auto mode_is = [&](uint32_t m) { return m == lane_trace ? in_trace : m == lane_restart ? in_restart : m == lane_retired ? in_retired : !(in_trace || in_restart || in_retired); };
+			const auto become = [&](uint32_t m) { in_trace = m == lane_trace, in_restart = m == lane_restart, in_retired = m == lane_retired; };
+#define RT_HIP_IS(m) mode_is(m)
+#define RT_HIP_BECOME(m) become(m)
+#endif
 
 			// all items of a tile are in: fold the chunk sums of each pixel in chunk order and write it (:195-200)
 			const auto fold_tile = [&](const float* sums, uint32_t x0, uint32_t y0)
@@ -508,11 +600,10 @@ namespace rt_hip
 					// sub-chunk items: every sample's value went to its own place (end_sample); the lane that brings a pixel's
 					// last item adds them up as the contract says — sixteen in sample order per chunk, chunks in chunk order
 					unsigned long long* const samples = item_sums + 2u * static_cast<size_t>(slot) * p.samples_per_pixel;
-					asm volatile("s_waitcnt vmcnt(0) ; the samples have left before the arrival is counted" ::: "memory");
-					const uint32_t before = __hip_atomic_fetch_add(&pixel_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					const uint32_t before = count_arrival(&pixel_done[slot]);
 					if (before + 1u == items_per_pixel)
 					{
-						__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+						last_arrival();
 						vec3 colour = { 0.0f, 0.0f, 0.0f };
 						for (uint32_t first = 0; first < p.samples_per_pixel; first += sample_chunk)
 						{
@@ -522,9 +613,7 @@ namespace rt_hip
 							for (; i + 8u <= end; i += 8u) // eight loads in flight, then eight additions in sample order
 							{
 								vec3 value[8];
-#pragma unroll
-								for (uint32_t k = 0; k < 8u; k++)
-									value[k] = read_sum(samples + 2u * (i + k));
+								read_sums8(samples + 2u * i, value);
 #pragma unroll
 								for (uint32_t k = 0; k < 8u; k++)
 									chunk_sum = chunk_sum + value[k];
@@ -533,8 +622,7 @@ namespace rt_hip
 								chunk_sum = chunk_sum + read_sum(samples + 2u * i);
 							colour = first ? colour + chunk_sum : chunk_sum;
 						}
-						__hip_atomic_store(&pixel_done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // as the next launch expects it
-						finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+						finish_pixel(colour, p, lx, ly, out_rgba, out_rgb); // (the counter stays: every launch zeroes its counters first)
 					}
 					return;
 				}
@@ -546,16 +634,14 @@ namespace rt_hip
 				const uint32_t chunk = (st.sample_end - 1u) / sample_chunk;
 				unsigned long long* const sums = item_sums + 2u * static_cast<size_t>(slot) * q.chunks;
 				publish_sum(sums + 2u * chunk, st.chunk_sum);
-				asm volatile("s_waitcnt vmcnt(0) ; the sum has left before the arrival is counted" ::: "memory");
-				const uint32_t before = __hip_atomic_fetch_add(&pixel_done[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				const uint32_t before = count_arrival(&pixel_done[slot]);
 				if (before + 1u == q.chunks)
 				{
-					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (no instruction: keeps the loads below the counter's answer)
+					last_arrival();
 					vec3 colour = read_sum(sums);
 					for (uint32_t c = 1; c < q.chunks; c++)
 						colour = colour + read_sum(sums + 2u * c);
-					__hip_atomic_store(&pixel_done[slot], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // as the next launch expects it
-					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb);
+					finish_pixel(colour, p, lx, ly, out_rgba, out_rgb); // (the counter stays: every launch zeroes its counters first)
 				}
 			};
 
@@ -566,11 +652,11 @@ namespace rt_hip
 				{
 					publish_sum(item_sums + 2u * (static_cast<size_t>(slot) * p.samples_per_pixel + st.sample), contribution);
 					if (++st.sample < st.sample_end)
-						mode = lane_restart;
+						RT_HIP_BECOME(lane_restart);
 					else
 					{
 						complete_item();
-						mode = lane_free;
+						RT_HIP_BECOME(lane_free);
 					}
 					return;
 				}
@@ -589,7 +675,7 @@ namespace rt_hip
 					else
 						st.chunk_sum = st.chunk_sum + contribution;
 					if (++st.sample < st.sample_end)
-						mode = lane_restart;
+						RT_HIP_BECOME(lane_restart);
 					else
 					{
 						if (!((st.sample - 1u) & 8u)) // first half: its partial sum
@@ -598,13 +684,13 @@ namespace rt_hip
 							slot_of_chunk[1] = st.chunk_sum.y;
 							slot_of_chunk[2] = st.chunk_sum.z;
 						}
-						mode = lane_free;
+						RT_HIP_BECOME(lane_free);
 					}
 					return;
 				}
 				st.chunk_sum = st.chunk_sum + contribution;
 				if (++st.sample < st.sample_end)
-					mode = lane_restart;
+					RT_HIP_BECOME(lane_restart);
 				else
 				{
 					if (ROLLING)
@@ -615,7 +701,7 @@ namespace rt_hip
 						slots[slot * 3u + 1u] = st.chunk_sum.y;
 						slots[slot * 3u + 2u] = st.chunk_sum.z;
 					}
-					mode = lane_free;
+					RT_HIP_BECOME(lane_free);
 				}
 			};
 
@@ -623,7 +709,7 @@ namespace rt_hip
 			{
 				// ---- closest-hit query for every lane that holds a ray (trace(), :160-162) -----------------------------------
 				RT_HIP_REGION(0); // a trip
-				const bool tracing = mode == lane_trace;
+				const bool tracing = RT_HIP_IS(lane_trace);
 				if (SCALAR_SEGMENTS)
 					wave_segments += static_cast<unsigned>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(tracing)));
 				candidate tiled_planes = { 0.0f, 0u, false };
@@ -806,7 +892,7 @@ namespace rt_hip
 
 
 				// ---- hand out items to free lanes (converged): a lane whose chunk just ended with a miss restarts right below ----
-				const unsigned long long asking = __builtin_amdgcn_ballot_w64(mode == lane_free);
+				const unsigned long long asking = __builtin_amdgcn_ballot_w64(RT_HIP_IS(lane_free));
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
 				// a free lane starts on chunk `chunk` of the pixel at (lx, ly) of this rank's rows
 				// (HALF: `chunk` counts half-chunks of 8 samples; one that lies wholly behind the last sample is empty)
@@ -823,7 +909,7 @@ namespace rt_hip
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
 					st.sample = chunk * item_samples;
 					st.sample_end = min(st.sample + item_samples, p.samples_per_pixel);
-					mode = lane_restart;
+					RT_HIP_BECOME(lane_restart);
 				};
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
 				const auto take_item = [&](uint32_t item, uint32_t x0, uint32_t y0)
@@ -840,11 +926,11 @@ namespace rt_hip
 				{
 					RT_HIP_REGION(6); // hand-out
 					const uint32_t rank = __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(asking >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(asking), 0u));
-					if (mode == lane_free)
+					if (RT_HIP_IS(lane_free))
 					{
 						slot = next_item + rank;
 						if (slot >= items)
-							mode = lane_retired;
+							RT_HIP_BECOME(lane_retired);
 						else
 						{
 							RT_HIP_REGION(7); // a lane takes an item: pixel coordinates, stream keys
@@ -859,7 +945,7 @@ namespace rt_hip
 					uint32_t want = static_cast<uint32_t>(__builtin_popcountll(asking));
 					if (q.lane_cap < 64u) // (wave-uniform) a sparse launch: this wave holds at most lane_cap rays, see choose_queue
 					{
-						const uint32_t holding = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(mode == lane_trace || mode == lane_restart)));
+						const uint32_t holding = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(RT_HIP_IS(lane_trace) || RT_HIP_IS(lane_restart))));
 						want = min(want, q.lane_cap > holding ? q.lane_cap - holding : 0u);
 					}
 					uint32_t served = 0; // asking lanes given an item so far, in rank order
@@ -883,7 +969,7 @@ namespace rt_hip
 							prefetched = fetch_items(counters, prefetched_count);
 						}
 						const uint32_t take = static_cast<uint32_t>(min(static_cast<unsigned long long>(want - served), block_end - block_next)); // >= 1
-						if (mode == lane_free && rank - served < take) // served <= rank < served + take
+						if (RT_HIP_IS(lane_free) && rank - served < take) // served <= rank < served + take
 						{
 							// item -> (pixel in hand-out order, chunk): pixel-major, so that a pixel's chunks are started together
 							const unsigned long long item = block_next + (rank - served);
@@ -905,10 +991,10 @@ namespace rt_hip
 						served += take;
 						block_next += take;
 					}
-					if (dry && mode == lane_free)
-						mode = lane_retired;
+					if (dry && RT_HIP_IS(lane_free))
+						RT_HIP_BECOME(lane_retired);
 				}
-				const bool queue_empty = __builtin_amdgcn_ballot_w64(mode != lane_retired) == 0;
+				const bool queue_empty = __builtin_amdgcn_ballot_w64(!RT_HIP_IS(lane_retired)) == 0;
 				if (NS == -1)
 				{
 					if (__syncthreads_and(queue_empty)) // the four waves leave together
@@ -917,7 +1003,7 @@ namespace rt_hip
 				else if (queue_empty)
 					break;
 
-				const bool restart = mode == lane_restart;
+				const bool restart = RT_HIP_IS(lane_restart);
 				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
 				{
 					RT_HIP_REGION(8); // the fused tail: two draws
@@ -1037,7 +1123,7 @@ namespace rt_hip
 						}
 						st.throughput = { 1.0f, 1.0f, 1.0f };
 						st.bounces_left = p.max_bounces;
-						mode = lane_trace;
+						RT_HIP_BECOME(lane_trace);
 					}
 					if (shade || restart)
 					{

@@ -140,7 +140,7 @@ namespace rt_hip
 	// What the big-scene kernels exchange chunk sums through (owned by the context, grown on demand):
 	//   item_sums   16 bytes per item of this rank's rows (a chunk sum on its way to the lane that folds the pixel);
 	//               not needed when a pixel is one chunk.  With sub-chunk items: 16 bytes per SAMPLE
-	//   pixel_done  one arrival counter per pixel; zero between launches (the folding lane puts it back)
+	//   pixel_done  one arrival counter per pixel; zeroed on the launch's own stream in front of every launch (render.hip)
 	struct rolling_buffers
 	{
 		unsigned long long* item_sums = nullptr;
@@ -200,7 +200,7 @@ namespace rt_hip
 						   uint32_t* d_rgba8,
 						   float* d_rgb_f32,
 						   device_counters* d_counters,
-						   const rolling_buffers& rolling, // big scenes: sized by rolling_buffer_bytes(), pixel_done zeroed once
+						   const rolling_buffers& rolling, // big scenes: sized by rolling_buffer_bytes(), pixel_done zeroed in front of the launch
 						   uint32_t compute_units, // of the device: the big-scene kernels are launched persistent
 						   launch_cache& cache,
 						   hipStream_t stream);

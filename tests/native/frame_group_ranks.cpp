@@ -11,9 +11,14 @@
 //   leaves    the last rank exits after 3 frames: the others must stop waiting at once (not at the deadline)
 //   absent    the last rank never joins: join must time out on the others and leave no name behind
 //   silent    the last rank stops calling after 3 frames without leaving: the deadline must end the wait
+//   killed    the last rank's process is killed (SIGKILL: no destructor runs) after 3 frames: the others must be told that
+//             its process is gone within a fraction of a second, long before the 20 s deadline
+//   stale     a block of the same name was left behind by an earlier run (initialised, every counter at its target, its
+//             creator gone): rank 0 must replace it and no rank may join the leftover — then 200 frames as in `frames`
 // Prints "OK: ..." and exits 0 when every rank behaved as the scenario demands.
 #include "../../rt_amd/csrc/frame_group.hpp"
 
+#include <signal.h>
 #include <sys/wait.h>
 
 #include <cstdlib>
@@ -79,6 +84,8 @@ namespace
 		const uint32_t n_frames = 200;
 		for (uint32_t f = 1; f <= n_frames; f++)
 		{
+			if (scenario == "killed" && rank == last && f == 4)
+				kill(getpid(), SIGKILL);
 			if ((scenario == "leaves" || scenario == "silent") && rank == last && f == 4)
 			{
 				if (scenario == "silent")
@@ -117,6 +124,7 @@ namespace
 				const bool expected = (scenario == "private" && f == 1 && group.why_broken().find("not a mapping") != std::string::npos)
 									  || (scenario == "mismatch" && f == 2 && group.why_broken().find("other arguments") != std::string::npos)
 									  || (scenario == "leaves" && f == 4 && waited < 2.0 && group.why_broken().find("left the group") != std::string::npos)
+									  || (scenario == "killed" && f == 4 && waited < 2.0 && group.why_broken().find("is gone") != std::string::npos)
 									  || (scenario == "silent" && f == 4 && waited >= 0.35 && waited < 1.9 && group.why_broken().find("waited 400 ms") != std::string::npos);
 				if (!expected)
 					std::fprintf(stderr, "rank %u frame %u: outcome %d after %.3f s: %s\n", rank, f, static_cast<int>(o), waited, group.why_broken().c_str());
@@ -130,7 +138,7 @@ namespace
 						return 1;
 					}
 		}
-		if (scenario != "frames")
+		if (scenario != "frames" && scenario != "stale")
 		{
 			std::fprintf(stderr, "rank %u: scenario %s ran to the end\n", rank, scenario.c_str());
 			return 1;
@@ -149,6 +157,25 @@ int main(int argc, char** argv)
 	const std::string buffer_name = "/rt_hip_test_frame_" + std::to_string(getpid());
 	if (!map_buffer(buffer_name.c_str(), true))
 		return 65;
+	if (scenario == "stale")
+	{
+		// what a run that crashed after its join would leave under this name: a finished child's pid as the creator
+		const pid_t ghost = fork();
+		if (ghost == 0)
+			_exit(0);
+		waitpid(ghost, nullptr, 0);
+		const int fd = shm_open(group_name.c_str(), O_CREAT | O_EXCL | O_RDWR, 0600);
+		if (fd < 0 || ftruncate(fd, sizeof(rt_hip::frame_group_block)) != 0)
+			return 66;
+		auto* old = static_cast<rt_hip::frame_group_block*>(mmap(nullptr, sizeof(rt_hip::frame_group_block), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0));
+		close(fd);
+		old->world = world;
+		old->creator_pid = static_cast<int32_t>(ghost);
+		old->joined.store(world);
+		old->entered.store(1000 * world), old->finished.store(1000 * world);
+		old->magic.store(rt_hip::frame_group_magic);
+		munmap(old, sizeof(rt_hip::frame_group_block));
+	}
 	std::vector<pid_t> children;
 	for (uint32_t rank = 0; rank < world; rank++)
 	{
@@ -162,7 +189,8 @@ int main(int argc, char** argv)
 	{
 		int status = 0;
 		waitpid(pid, &status, 0);
-		if (!WIFEXITED(status) || WEXITSTATUS(status) != 0)
+		const bool killed_on_purpose = scenario == "killed" && pid == children.back() && WIFSIGNALED(status) && WTERMSIG(status) == SIGKILL;
+		if (!killed_on_purpose && (!WIFEXITED(status) || WEXITSTATUS(status) != 0))
 			bad++;
 	}
 	shm_unlink(buffer_name.c_str());

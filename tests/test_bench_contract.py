@@ -30,6 +30,28 @@ def run_bench(args, launcher=None, timeout=600, expect_rc=0):
     return json.loads(lines[0])
 
 
+@pytest.mark.parametrize("ranks", [1, 3])
+def test_torchrun_flow_starts_one_child_per_form_and_rank_without_touching_a_gpu(ranks):
+    """The N > 1 flow of bench.py on the CPU (RT_BENCH_DRY_RUN): the torchrun-launched processes start one child per form and
+    rank, the children of a form meet on a port of their own, rank 0 collects the verdicts — and, nothing having been measured,
+    prints a line without a value and exits non-zero."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(port), str(ROOT / "bench.py"),
+           "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--library-deadline-s", "120"]
+    out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600, env=dict(os.environ, RT_BENCH_DRY_RUN="1"))
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1 and out.returncode != 0, (out.returncode, out.stdout, out.stderr[-2000:])
+    line = json.loads(lines[0])
+    assert line["value"] is None and line["n_gpus"] == ranks
+    assert set(line["paths"]) == {"library", "shared_frame", "torch"}
+    assert all(f"dry run: {ranks} rank(s) met" in line["paths"][form]["status"] for form in line["paths"])
+    assert len({line["paths"][form]["status"] for form in line["paths"]}) == 3  # three rendezvous, three ports
+
+
 @pytest.mark.gpu
 def test_single_gpu_line_has_the_contract_keys_roofline_and_cpu_baseline():
     line = run_bench(["--gpus", "1", "--steps", "3", "--warmup", "1", "--spp", "32", "--cpu-baseline-seconds", "1"])

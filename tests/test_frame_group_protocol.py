@@ -36,14 +36,23 @@ def test_frames_are_complete_when_rank_0_returns(ranks_exe, world):
     assert run.returncode == 0 and run.stdout.startswith("OK:"), run.stdout + run.stderr
 
 
-@pytest.mark.parametrize("scenario", ["private", "mismatch", "leaves", "absent", "silent"])
+@pytest.mark.parametrize("scenario", ["private", "mismatch", "leaves", "absent", "silent", "killed"])
 def test_a_rank_that_misbehaves_ends_the_frame_on_every_rank(ranks_exe, scenario):
-    """private buffer / other arguments / a rank that leaves / never joins / goes silent: nobody hangs, everybody is told why."""
+    """private buffer / other arguments / a rank that leaves / never joins / goes silent / is killed outright (its
+    pid is in the block — no need to wait for the deadline): nobody hangs, everybody is told why."""
     run = subprocess.run([str(ranks_exe), scenario, "4"], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0 and run.stdout.startswith("OK:"), run.stdout + run.stderr
 
 
-@pytest.mark.parametrize("scenario", ["frames", "private", "leaves", "silent"])
+@pytest.mark.parametrize("world", [2, 4])
+def test_a_block_left_behind_under_the_same_name_is_replaced_not_joined(ranks_exe, world):
+    """non-zero ranks used to attach to ANY existing object of that name — a leftover of a crashed run already has
+    its magic set and its counters at their targets, so they sailed through the join while rank 0 failed with EEXIST."""
+    run = subprocess.run([str(ranks_exe), "stale", str(world)], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and run.stdout.startswith("OK:"), run.stdout + run.stderr
+
+
+@pytest.mark.parametrize("scenario", ["frames", "private", "leaves", "silent", "killed", "stale"])
 def test_the_protocol_is_clean_under_address_and_undefined_behaviour_sanitizers(sanitized_exe, scenario):
     run = subprocess.run([str(sanitized_exe), scenario, "3"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0 and run.stdout.startswith("OK:") and "ERROR: AddressSanitizer" not in run.stderr and "runtime error" not in run.stderr, run.stdout + run.stderr[-3000:]
