@@ -62,7 +62,7 @@ def main():
             if f == 2 and rank == world - 1 and mode == "dies":
                 sys.stdout.write(json.dumps(result) + "\n")
                 sys.stdout.flush()
-                os._exit(0)  # no destructor runs: the others only have their deadline
+                os._exit(0)  # no destructor runs: the others find its process gone (or, at the latest, their deadline)
             if f == 2 and rank == world - 1 and mode == "leaves":
                 tracer.close()
                 break

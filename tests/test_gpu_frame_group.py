@@ -184,8 +184,10 @@ def test_a_rank_that_leaves_or_dies_does_not_hang_the_others(tmp_path):
     results, _ = run_group(tmp_path, 3, 64, 40, 1, frames=3, mode="dies", deadline_ms=1500)
     assert time.time() - t0 < 60
     assert [r["frames_done"] for r in results] == [1, 1, 1]
-    assert all("waited 1500 ms" in r["error"] for r in results[:2]), results
-    assert any("RT_HIP_TIMEOUT" in r["error"] for r in results[:2])
+    # (round 4: the others no longer have only their deadline — the dead rank's pid is in the group's block, and a rank that
+    # has waited for milliseconds looks whether the processes it waits for still exist; the deadline stays the backstop)
+    assert all("rank 2's process" in r["error"] and "is gone" in r["error"] or "waited 1500 ms" in r["error"] for r in results[:2]), results
+    assert any("is gone" in r["error"] for r in results[:2])
 
 
 def test_join_times_out_when_a_rank_stays_away():
