@@ -186,7 +186,7 @@ namespace rt_hip
 				std::memcpy(to_ + at, from_ + at, std::min(band_bytes_, bytes_ - at));
 			}
 			else
-				carry_band(bands_ - 1u - claimed); // the launches hand their tiles out bottom row first
+				carry_band(bottom_first_ ? bands_ - 1u - claimed : claimed);
 			bands_done_.fetch_add(1, std::memory_order_release);
 		}
 	}
@@ -221,12 +221,13 @@ namespace rt_hip
 		}
 	}
 
-	void pixel_carrier::begin(uint32_t* from, uint32_t* to, size_t words)
+	void pixel_carrier::begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first)
 	{
 		if (in_flight_)
 			abandon();
 		close();
 		kind_ = carry_pixels;
+		bottom_first_ = bottom_first;
 		from_ = reinterpret_cast<unsigned char*>(from);
 		to_ = reinterpret_cast<unsigned char*>(to);
 		bytes_ = words * sizeof(uint32_t);

@@ -34,7 +34,9 @@ namespace rt_hip
 
 		// A frame of `words` pixels begins: `from` (64-byte aligned, module-owned, ALL ZERO) is about to be stored into by
 		// the device; `to` is the caller's buffer.  Returns at once; the helpers start looking at the frame.
-		void begin(uint32_t* from, uint32_t* to, size_t words);
+		// `bottom_first`: the order the bands are looked at — the render launches hand their tiles out bottom row first; a frame
+		// whose bulk arrives through the multi-GPU assemble kernel fills from the top.
+		void begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first = true);
 		// Everything the device stored is visible to this thread now (the stream has drained): carry over what is left.
 		// Returns when every word is in `to` and `from` is all zero again.
 		void finish();
@@ -70,6 +72,7 @@ namespace rt_hip
 
 		// the job in flight: written by the caller's thread while the job is closed, read by threads that entered an open job
 		uint32_t kind_ = carry_pixels;
+		bool bottom_first_ = true;
 		unsigned char* from_ = nullptr;
 		unsigned char* to_ = nullptr;
 		size_t bytes_ = 0, bands_ = 0, band_bytes_ = 0;

@@ -336,7 +336,12 @@ namespace rt_hip
 			__hip_atomic_store(reinterpret_cast<uint32_t*>(slot + 1), __float_as_uint(sum.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
 			const v4f value = { sum.x, sum.y, sum.z, 0.0f };
-			asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(slot), "v"(value) : "memory");
+			// The two wait states behind the store are part of it: a VMEM store of more than 64 bits reads its data registers
+			// after issue, and a vector instruction that overwrites them within two wait states corrupts the stored value
+			// (gfx940+ "VMEM store data hazard").  The compiler pads its own stores; it cannot see into this one — found the
+			// hard way: the sm kernels' next instruction recycled the value's upper half for an address, and z arrived as a
+			// pointer's low word (profiles/r04/case0_bisect.txt).
+			asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(slot), "v"(value) : "memory");
 #endif
 		}
 		__device__ __forceinline__ vec3 read_sum(unsigned long long* slot)

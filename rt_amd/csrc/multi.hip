@@ -86,7 +86,8 @@ namespace rt_hip
 			}
 			if (!mapped_frame)
 			{
-				if (const rt_hip_status st = delivery->begin(pixels_rgba8888, pixels, &mapped_frame))
+				// (gathered: the bulk of the frame arrives through the assemble kernel, top rows first; direct: bottom first)
+				if (const rt_hip_status st = delivery->begin(pixels_rgba8888, pixels, &mapped_frame, root->direct_frame && n == static_cast<int>(world) && !rgb_f32))
 					return st;
 				staged.delivery = delivery;
 			}

@@ -32,7 +32,7 @@ struct frame_case
 };
 
 // the "device": stores tile after tile, roughly bottom row first, each pixel one relaxed atomic 32-bit store
-static void device_stores(uint32_t* staging, const frame_case& f, uint64_t frame, unsigned seed, size_t stop_after_tiles)
+static void device_stores(uint32_t* staging, const frame_case& f, uint64_t frame, unsigned seed, size_t stop_after_tiles, bool bottom_first)
 {
 	const size_t tiles_x = (f.width + f.tile_w - 1) / f.tile_w, tiles_y = (f.height + f.tile_h - 1) / f.tile_h;
 	std::vector<size_t> order(tiles_x * tiles_y);
@@ -47,7 +47,7 @@ static void device_stores(uint32_t* staging, const frame_case& f, uint64_t frame
 	{
 		if (done++ == stop_after_tiles)
 			return;
-		const size_t ty = tiles_y - 1 - t / tiles_x, tx = t % tiles_x;
+		const size_t ty = bottom_first ? tiles_y - 1 - t / tiles_x : t / tiles_x, tx = t % tiles_x; // (top first: the multi-GPU assemble kernel)
 		for (size_t y = ty * f.tile_h; y < std::min(f.height, (ty + 1) * f.tile_h); y++)
 			for (size_t x = tx * f.tile_w; x < std::min(f.width, (tx + 1) * f.tile_w); x++)
 				__atomic_store_n(&staging[y * f.width + x], pixel_of(frame, y * f.width + x), __ATOMIC_RELAXED);
@@ -77,8 +77,9 @@ int main(int argc, char** argv)
 				const bool abandon = frame == 2 && (round & 1);
 				for (size_t i = 0; i < words; i++)
 					to[i] = 0x000000FFu; // the caller's pre-cleared black
-				carrier.begin(staging, to, words);
-				std::thread device(device_stores, staging, std::cref(f), frame + 10 * round, static_cast<unsigned>(frame * 7919 + round), abandon ? (words > 64 ? 17 : 0) : ~size_t(0));
+				const bool bottom_first = ((round + frame) & 1) == 0;
+				carrier.begin(staging, to, words, bottom_first);
+				std::thread device(device_stores, staging, std::cref(f), frame + 10 * round, static_cast<unsigned>(frame * 7919 + round), abandon ? (words > 64 ? 17 : 0) : ~size_t(0), bottom_first);
 				device.join(); // = the stream has drained
 				if (abandon)
 				{
