@@ -497,16 +497,18 @@ namespace rt_hip
 			//   free    - between items                       restart - has a sample to start (needs a primary ray)
 			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
 			enum : uint32_t { lane_free, lane_restart, lane_trace, lane_retired };
-#ifdef RT_HIP_MODE_REGISTER
-			uint32_t mode = lane_free; // (round 3's form, kept for the A/B: the mode as a number in a vector register)
+#ifndef RT_HIP_MODE_MASKS
+			uint32_t mode = lane_free; // the mode as a number in a vector register
 #define RT_HIP_IS(m) (mode == (m))
 #define RT_HIP_BECOME(m) (mode = (m))
 #else
-			// Round 4's one structural experiment ("fewer lane modes"): the mode is not a per-lane NUMBER that every
-			// use has to compare (a v_cmp per question, a v_cndmask / v_mov per change) but three lane MASKS — the compiler keeps
-			// a bool that lives across loop trips as a 64-bit scalar pair and combines such masks on the scalar unit, which has
-			// slots to spare here (0.40 scalar per vector instruction) while the vector unit is the one at its issue limit.
-			// free = none of the three.  Same transitions, same frames.
+			// Round 4's one structural experiment ("fewer lane modes"), NOT adopted: the mode not as a per-lane
+			// NUMBER that every use compares (a v_cmp per question, a v_cndmask / v_mov per change) but as three lane MASKS, which
+			// the compiler keeps as 64-bit scalar pairs across loop trips and combines on the scalar unit.  Same frames; the
+			// vector instruction count did not move (2.204 G against 2.207 G per headline launch: the compares were already
+			// folded into the branches' masks), the scalar one rose by 42 % (1.264 G against 0.891 G) — and the kernel went
+			// from 2.64 to 2.85 ms: the scalar unit is NOT free here, its instructions sit on the loop's critical path between
+			// the vector ones (profiles/r04/ab_mode_masks.txt).  Kept behind this switch for the record.
 			bool in_trace = false, in_restart = false, in_retired = false;
 			const auto mode_is = [&](uint32_t m) { return m == lane_trace ? in_trace : m == lane_restart ? in_restart : m == lane_retired ? in_retired : !(in_trace || in_restart || in_retired); };
 			const auto become = [&](uint32_t m) { in_trace = m == lane_trace, in_restart = m == lane_restart, in_retired = m == lane_retired; };
