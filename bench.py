@@ -135,6 +135,7 @@ def parse_args():
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
     ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
     ap.add_argument("--resident", action="store_true", help="force the LDS-resident kernel (what a scene of 9 to 704 primitives gets; scenes of up to 8 take the scalar-register kernel otherwise)")
+    ap.add_argument("--tilt", action="store_true", help="single-process only: look down by 8.5 degrees from (0.2, 1.2, 3.0) instead of the scene's axis-aligned camera — the inverse view-projection then carries rounding noise in w's x / y terms (every frame of an interactive session): the general-camera build of the kernels")
     ap.add_argument("--fast", action="store_true", help="RT_HIP_FLAG_FAST: the tolerance-bound arithmetic (raw v_rsq/v_rcp), a second bench line; never the parity contract")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--frames-in-flight", type=int, default=1, help="torchrun mode with --gather torch only. 1 (default): one frame at a time, as a blocking render() caller sees it; 2: consecutive frames alternate between two streams (a throughput experiment: reported under `config`, never the default)")
@@ -173,7 +174,7 @@ def make_build_line(args, pod, n_gpus, single_process):
         traffic = None
         issue = None
         forced = "_tiled" if args.tiled else "_streamed" if args.streamed else "_resident" if args.resident else ""
-        counters_key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}{forced}" + ("_fast" if args.fast else "")
+        counters_key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}{forced}" + ("_fast" if args.fast else "") + ("_tilt" if args.tilt else "")
         try:
             from tools.kernel_sources_hash import kernel_sources_sha16
 
@@ -240,7 +241,7 @@ def make_build_line(args, pod, n_gpus, single_process):
             "dtype": "f32",
             "data": "synthetic (generated sphere field, SURVEY.md §8d)" if synthetic else f"the reference's scene file scenes/{args.scene}.toml (no dataset; nothing is learned or loaded beyond the scene)",
             "config": {
-                "workload": f"scenes/{args.scene}.toml {args.width}x{args.height} {args.spp} spp max_bounces {args.max_bounces} seed {args.seed}",
+                "workload": f"scenes/{args.scene}.toml {args.width}x{args.height} {args.spp} spp max_bounces {args.max_bounces} seed {args.seed}" + (" camera tilted (w varies over the frame)" if args.tilt else ""),
                 "step": "one blocking render(): host scene in (columns fingerprinted, resident in HBM since warm-up), finished frame in the caller's host buffer out, one frame at a time",
                 "spheres": pod.n_spheres,
                 "planes": pod.n_planes,
@@ -285,6 +286,8 @@ def single_process_main(args) -> None:
     device = 0
     torch.cuda.set_device(device)
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
+    if args.tilt:
+        scene.set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
     pod = scene.describe(args.width, args.height)
     flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
     if args.fast:

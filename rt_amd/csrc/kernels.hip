@@ -61,6 +61,9 @@
 #ifndef RT_HIP_WAVES_RESIDENT
 #define RT_HIP_WAVES_RESIDENT 7
 #endif
+#ifndef RT_HIP_PERSISTENT_WAVES_CAP
+#define RT_HIP_PERSISTENT_WAVES_CAP 5 // workgroups per CU of the persistent (big-scene) launches: see launch_queue_sm
+#endif
 
 // Region counters (tools/region_profile.py; built only as an experiment variant, never in the product): how often each
 // part of a loop trip runs and with how many lanes — the dynamic side of profiles/r02/isa_trip_breakdown.txt.
@@ -412,7 +415,14 @@ namespace rt_hip
 		// scenes/dielectric.toml:17-19) stay on the scalar-operand path.  Which slot is what is known at compile time: no
 		// kind check at run time, and the no-plane variants are what they were.  NS + NP <= 8, NP <= 3 (more planes, or planes
 		// without a sphere, take the LDS-resident kernel).
-		template <int NS, bool SM, bool HALF = false, int NP = 0>
+		// GC (small kernel only; round 4): the GENERAL camera — an inverse view-projection whose w varies over the frame takes
+		// the per-sample division (camera.hpp:42-48) instead of contract v3's affine primary rays.  rt's own matrix is the
+		// float inverse of projection x view (camera.hpp:122-137): for a camera that is not axis-aligned its last row comes
+		// out with rounding noise in the x and y terms (-4.5e-7 against a w of 0.001 at the far plane: 4.5e-4 relative — not
+		// something to round away), i.e. every frame while the user looks around.  Those frames used to fall to the
+		// LDS-resident kernel (+35 % on basic.toml); now they keep the scalar-register kernel, in a build of it that carries
+		// the 18 scalars of the general form INSTEAD of the 18 of the affine one (both would not fit its scalar registers).
+		template <int NS, bool SM, bool HALF = false, int NP = 0, bool GC = false>
 		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
@@ -1097,12 +1107,12 @@ namespace rt_hip
 						const float px = fma(jx, random_scale, st.fx); // == fx + jx * 2^-24: the product is exact
 						const float py = fma(jy, random_scale, st.fy);
 						// rt's camera (w constant over the frame): near point and near-to-far vector are affine in (px, py) —
-						// contract v3, constants from the host.  Any other matrix goes through the per-sample division; that
-						// path exists in the LDS / big-scene kernels only (the launch code never picks the scalar-register
-						// kernel for such a frame): as kernel arguments its 18 scalars would cost the small kernels, whose
-						// loop lives on its scalar registers, a spill per lane mask.
-						constexpr bool GENERAL_CAMERA = NS <= 0;
-						if (!GENERAL_CAMERA || p.uniform_w) // (wave-uniform: a kernel argument)
+						// contract v3, constants from the host.  Any other matrix goes through the per-sample division.  The LDS /
+						// big-scene kernels carry both forms; a scalar-register kernel is built for ONE of them (GC): as kernel
+						// arguments the two sets of 18 scalars together would cost its loop, which lives on its scalar
+						// registers, a spill per lane mask.
+						constexpr bool AFFINE_ONLY = NS > 0 && !GC, GENERAL_ONLY = NS > 0 && GC;
+						if (AFFINE_ONLY || (!GENERAL_ONLY && p.uniform_w)) // (wave-uniform: a kernel argument)
 						{
 							st.origin = { fma(p.ray_o1[0], px, fma(p.ray_o2[0], py, p.ray_o0[0])), fma(p.ray_o1[1], px, fma(p.ray_o2[1], py, p.ray_o0[1])),
 										  fma(p.ray_o1[2], px, fma(p.ray_o2[2], py, p.ray_o0[2])) };
@@ -1331,7 +1341,7 @@ namespace rt_hip
 
 #endif // !RT_HIP_FAST_BUILD
 
-		template <int NS, bool SM, int NP = 0>
+		template <int NS, bool SM, int NP = 0, bool GC = false>
 		void launch_queue_sm(const frame_params& frame,
 							 const queue_params& queue,
 							 const small_scene& small,
@@ -1368,6 +1378,12 @@ namespace rt_hip
 						asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes);
 					if (asked != hipSuccess || per_cu < 1)
 						per_cu = 4;
+					// Not more waves than the kernels were compiled for (5 per SIMD = 5 workgroups per CU), even when the register
+					// allocation of a build happens to leave room for a sixth: round 4's streamed kernel came out at 84 VGPRs, the
+					// runtime started 6 144 waves instead of 5 120 — and config 5 took 5.46 s instead of 5.10 (more waves walking
+					// the 1.6 MB sphere table at their own positions through the same scalar cache and L2; lanes active 96.0 %
+					// against 99.0 %: profiles/r04/persistent_waves_ab.txt).
+					per_cu = std::min(per_cu, RT_HIP_PERSISTENT_WAVES_CAP);
 					(void)hipGetLastError();
 					known.lds_bytes = lds_bytes;
 					known.per_cu = per_cu;
@@ -1378,14 +1394,14 @@ namespace rt_hip
 			{
 				if (queue.halves)
 				{
-					hipLaunchKernelGGL((render_queue<NS, SM, true, NP>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
+					hipLaunchKernelGGL((render_queue<NS, SM, true, NP, GC>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 					return;
 				}
 			}
-			hipLaunchKernelGGL((render_queue<NS, SM, false, NP>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
+			hipLaunchKernelGGL((render_queue<NS, SM, false, NP, GC>), grid, dim3(block_threads), lds_bytes, stream, frame, queue, small, scene, scene.primitive_geometry, d_rgba8, d_rgb_f32, d_counters, rolling.item_sums, rolling.pixel_done);
 		}
 
-		template <int NS, int NP = 0>
+		template <int NS, int NP = 0, bool GC = false>
 		void launch_queue(bool sm,
 						  const frame_params& frame,
 						  const queue_params& queue,
@@ -1403,10 +1419,10 @@ namespace rt_hip
 		{
 #ifndef RT_HIP_FAST_BUILD // (the API refuses RT_HIP_FLAG_FAST together with RT_HIP_FLAG_SM_MATERIALS)
 			if (sm)
-				launch_queue_sm<NS, true, NP>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+				launch_queue_sm<NS, true, NP, GC>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			else
 #endif
-				launch_queue_sm<NS, false, NP>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+				launch_queue_sm<NS, false, NP, GC>(frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 		}
 	}
 
@@ -1418,9 +1434,10 @@ namespace rt_hip
 			return RT_HIP_KERNEL_STREAMED;
 		if (flags & RT_HIP_FLAG_FORCE_TILED)
 			return RT_HIP_KERNEL_TILED;
-		// (the scalar-register kernel knows rt's camera only — a matrix whose w varies over the frame takes the LDS kernel)
-		// up to 8 primitives: at least one sphere, at most three planes (round 4: a plane no longer pushes a scene off this kernel)
-		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && uniform_w && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
+		// up to 8 primitives: at least one sphere, at most three planes (round 4: neither a plane nor a camera whose w varies
+		// over the frame pushes a scene off this kernel any more)
+		(void)uniform_w;
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
 		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against
@@ -1618,7 +1635,9 @@ namespace rt_hip
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
 			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
-#define RT_HIP_LAUNCH_SMALL(N, P) launch_queue<N, P>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)
+#define RT_HIP_LAUNCH_SMALL(N, P)                                                                                                    \
+	(frame.uniform_w ? launch_queue<N, P, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)  \
+					 : launch_queue<N, P, true>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream))
 #define RT_HIP_LAUNCH_SMALL_SPHERES(P, N_MAX)                                                                                        \
 	switch (scene.n_spheres)                                                                                                         \
 	{                                                                                                                                \

@@ -169,10 +169,29 @@ def test_projective_matrix_with_varying_w_takes_the_per_sample_division(tracer):
     m = np.array(pod.inverse_view_projection[:], dtype=np.float32).reshape(4, 4)
     m[3, 0], m[3, 1] = 3.0, -2.0  # w now depends on x and y
     pod.inverse_view_projection = (C.c_float * 16)(*m.reshape(-1))
-    for flags in (0, FORCE_RESIDENT):
-        got_rgba, got_rgb, _ = tracer.render(pod, 96, 54, seed=12, flags=flags, want_rgb=True)
+    for flags in (0, FORCE_RESIDENT, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS):
+        got_rgba, got_rgb, stats = tracer.render(pod, 96, 54, seed=12, flags=flags, want_rgb=True)
         want_rgba, want_rgb, _ = oracle.render(pod, 96, 54, seed=12)
+        # (round 4: such a matrix keeps the scalar-register kernel — its general-camera build)
+        assert stats["kernel"] == ("resident" if flags & FORCE_RESIDENT else "small")
         assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "non-uniform w")
+
+
+def test_a_camera_that_is_not_axis_aligned_keeps_the_scalar_register_kernel(tracer):
+    """rt's inverse view-projection is the float inverse of projection x view (reference src/camera.hpp:122-137): for a tilted
+    camera its last row comes out with rounding noise in the x and y terms, so w is NOT constant over the frame and the primary
+    rays take the per-sample division — every frame while the user looks around (src/main.cpp:265-311).  Those frames used to
+    fall to the LDS-resident kernel; they now run the general-camera build of the scalar-register kernel, bit-exact."""
+    width, height = 160, 90
+    scene = rt_amd.Scene.named("basic_plane").set_sampling(24).set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+    pod = scene.describe(width, height)
+    assert pod.inverse_view_projection[13] != 0.0  # the noise this test is about
+    for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, SM):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=41, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=41, sm_materials=bool(flags & SM))
+        assert stats["kernel"] == "small"
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"tilted camera, flags {flags}")
+        assert stats["segments"] == want_stats["segments"]
 
 
 @pytest.mark.parametrize("count", [1, 2, 8, 9])
@@ -220,9 +239,10 @@ def test_every_sphere_and_plane_count_of_the_scalar_register_kernel(tracer, n_sp
         n /= np.linalg.norm(n)
         planes.append((*n, rng.uniform(2.0, 6.0), rng.integers(0, n_mat)))
     width, height, spp, bounces = 96, 54, int(rng.integers(3, 40)), int(rng.integers(2, 9))
-    camera = rt_amd.Scene.parse("").set_camera((0.0, 1.0, 3.0), (0.0, -0.2, -1.0))
+    # (odd cases: a camera whose matrix carries rounding noise in w's x / y terms — the general-camera build of the kernel)
+    camera = rt_amd.Scene.parse("").set_camera((0.0, 1.0, 3.0), (0.0, -0.2, -1.0)) if (n_spheres + n_planes) % 2 == 0 else rt_amd.Scene.parse("").set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
     ivp = camera.describe(width, height).inverse_view_projection[:]
-    assert ivp[12] == 0.0 and ivp[13] == 0.0  # w constant over the frame: what the scalar-register kernel asks of the camera
+    assert (ivp[12] == 0.0 and ivp[13] == 0.0) == ((n_spheres + n_planes) % 2 == 0)
     pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
     in_registers = n_spheres >= 1 and n_planes <= 3 and n_spheres + n_planes <= 8
     for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, capi.RT_HIP_FLAG_FORCE_WHOLE_CHUNKS, SM):

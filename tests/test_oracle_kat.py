@@ -550,3 +550,25 @@ def test_normalize_of_unit_vectors_stays_put():
     d = (v[:, 2].astype(np.float64) * v[:, 2] + d).astype(np.float32)
     scaled = v * oracle.inv_sqrt(d)[:, None]
     assert np.max(np.abs(scaled.view(np.int32).astype(np.int64) - v.view(np.int32).astype(np.int64))) <= 1
+
+
+def test_plane_lanes_the_kernels_call_hopeless_are_rejected_by_the_reference_rule():
+    """rt_amd/csrc/scan.hpp test_plane skips the division t = -num / den for lanes it calls hopeless — num finite and num, den
+    both >= 0 or both <= 0 — because test_planes (reference mg_ray_tracer.cpp:46-52) would reject them anyway: `hits()` needs
+    t >= 0 and the scan drops t < 0.001.  Checked here on the whole zoo of binary32 classes (zeros of both signs, subnormals,
+    huge values, infinities, NaNs) crossed with itself and on a million random pairs: hopeless => t is not NaN and t < 0.001."""
+    rng = np.random.default_rng(11)
+    special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1e-6, -1e-6, 0.001, -0.001, 1.0, -1.0, 3e38, -3e38, np.inf, -np.inf, np.nan], dtype=np.float32)
+    num = np.concatenate([np.repeat(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
+    den = np.concatenate([np.tile(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
+    finite = np.isfinite(num)
+    hopeless = (finite & (num >= 0) & (den > 0)) | (finite & (num <= 0) & (den < 0))
+    with np.errstate(all="ignore"):
+        t = (-num) / den
+    assert hopeless.sum() > 400_000
+    assert not np.isnan(t[hopeless]).any()
+    assert (t[hopeless] < np.float32(0.001)).all()
+    # and the lanes that are NOT hopeless include every lane the reference would accept
+    crosses = ~(np.abs(den) <= np.float32(1e-6))
+    accepted = crosses & ~(t < np.float32(0.001))  # (a NaN distance is "accepted" by the negated comparison, as in the reference)
+    assert not (accepted & hopeless).any()
