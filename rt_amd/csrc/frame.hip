@@ -285,6 +285,13 @@ namespace rt_hip
 		return ok();
 	}
 
+	void frame_delivery::finish()
+	{
+		carrier.finish();
+		if (debug_frame())
+			std::fprintf(stderr, "rt_hip: frame delivered: %zu of its 64 KB bands had been carried over before the stream drained\n", carrier.early_bands());
+	}
+
 	uint32_t* frame_delivery::view_on(int device)
 	{
 		void* view = nullptr;

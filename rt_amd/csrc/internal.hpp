@@ -323,7 +323,7 @@ namespace rt_hip
 		rt_hip_status begin(uint32_t* caller_pixels, size_t pixels, uint32_t** out_device_view, bool bottom_first = true);
 		// the same frame as `device` sees it (direct frames of several GPUs); leaves that device current; NULL on failure
 		uint32_t* view_on(int device);
-		void finish() { carrier.finish(); }
+		void finish();
 		void abandon()
 		{
 			carrier.abandon();

@@ -1378,11 +1378,10 @@ namespace rt_hip
 						asked = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_queue<NS, SM>, static_cast<int>(block_threads), lds_bytes);
 					if (asked != hipSuccess || per_cu < 1)
 						per_cu = 4;
-					// Not more waves than the kernels were compiled for (5 per SIMD = 5 workgroups per CU), even when the register
-					// allocation of a build happens to leave room for a sixth: round 4's streamed kernel came out at 84 VGPRs, the
-					// runtime started 6 144 waves instead of 5 120 — and config 5 took 5.46 s instead of 5.10 (more waves walking
-					// the 1.6 MB sphere table at their own positions through the same scalar cache and L2; lanes active 96.0 %
-					// against 99.0 %: profiles/r04/persistent_waves_ab.txt).
+					// Not more workgroups than the kernels were compiled for (5 waves per SIMD = 5 workgroups per CU), even when the
+					// register allocation of a build happens to leave room for a sixth (round 4 saw 6 144 waves instead of 5 120
+					// on one build): the launch's shape should not depend on that.  Measured, it makes no difference either way
+					// (config 5: 5.479 against 5.476 s, profiles/r04/persistent_waves_ab.txt).
 					per_cu = std::min(per_cu, RT_HIP_PERSISTENT_WAVES_CAP);
 					(void)hipGetLastError();
 					known.lds_bytes = lds_bytes;

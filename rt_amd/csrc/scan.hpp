@@ -63,10 +63,11 @@ namespace rt_hip
 	// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
 	// The quotient t = -num / den is a correctly rounded division (~18 issue slots) and is only worth taking for a lane whose
 	// plane can still be ACCEPTED.  A lane is hopeless — t < min_hit_dist for certain, and no NaN can come of the division —
-	// when num is finite and num and den are both >= 0 or both <= 0 (either zero counts as both): then -num / den is <= 0, -0
-	// or +0.  Rays that point away from a ground plane — every sky tile's primary rays, most bounces off the ground — are
-	// hopeless wave-wide, and the division is skipped with one ballot.  A NaN or an infinity in num falls into neither class
-	// and takes the division as before: results are the same bits for every input (round 4; basic_plane.toml 3.17 -> 2.9x ms).
+	// when num * den is a positive FINITE number (one multiply, one v_cmp_class): then num and den are both finite, non-zero
+	// and of one sign, and -num / den is negative.  Rays that point away from a ground plane — every sky tile's primary
+	// rays, most bounces off the ground — are hopeless wave-wide, and the division is skipped with one ballot.  Anything
+	// else (a zero, an infinity, a NaN, a product that under- or overflows) takes the division as before: the results are the
+	// same bits for every input (tests/test_oracle_kat.py::test_plane_lanes_the_kernels_call_hopeless_...).
 	__device__ __forceinline__ void test_plane(candidate& best, vec3 o, vec3 d, float4 pl, uint32_t index)
 	{
 		const vec3 n = { pl.x, pl.y, pl.z };
@@ -75,10 +76,7 @@ namespace rt_hip
 		if (__builtin_amdgcn_ballot_w64(crosses) != 0)
 		{
 			const float num = dot(n, o) + pl.w;
-			// v_cmp_class_f32: bit 3 -normal, 4 -subnormal, 5 -0, 6 +0, 7 +subnormal, 8 +normal
-			const bool num_not_negative = __builtin_amdgcn_class(num, 0x1E0); // finite and >= 0 (or -0)
-			const bool num_not_positive = __builtin_amdgcn_class(num, 0x078); // finite and <= 0 (or +0)
-			const bool hopeless = (num_not_negative && den > 0.0f) || (num_not_positive && den < 0.0f);
+			const bool hopeless = __builtin_amdgcn_class(num * den, 0x180); // v_cmp_class_f32: bit 7 +subnormal, bit 8 +normal
 			const bool in_reach = crosses && !hopeless;
 			if (__builtin_amdgcn_ballot_w64(in_reach) != 0)
 			{

@@ -513,6 +513,11 @@ def test_config4_basic_4k_tile_split(tracer):
     import os
 
     spp = 256 if len(os.sched_getaffinity(0)) >= 64 else 8
+    print(f"config 4 at {spp} spp ({len(os.sched_getaffinity(0))} host threads for the oracle frame; BASELINE.json's figure is 256)")
+    if spp != 256:
+        import warnings
+
+        warnings.warn(f"test_config4_basic_4k_tile_split ran at {spp} spp, not BASELINE.json's 256: this host has {len(os.sched_getaffinity(0))} threads for the oracle")
     check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(spp), 3840, 2160, seed=1, oracle_world=16)
 
 

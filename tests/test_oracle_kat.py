@@ -553,18 +553,18 @@ def test_normalize_of_unit_vectors_stays_put():
 
 
 def test_plane_lanes_the_kernels_call_hopeless_are_rejected_by_the_reference_rule():
-    """rt_amd/csrc/scan.hpp test_plane skips the division t = -num / den for lanes it calls hopeless — num finite and num, den
-    both >= 0 or both <= 0 — because test_planes (reference mg_ray_tracer.cpp:46-52) would reject them anyway: `hits()` needs
+    """rt_amd/csrc/scan.hpp test_plane skips the division t = -num / den for lanes it calls hopeless — the binary32 product
+    num * den is a positive finite number — because test_planes (reference mg_ray_tracer.cpp:46-52) would reject them anyway: `hits()` needs
     t >= 0 and the scan drops t < 0.001.  Checked here on the whole zoo of binary32 classes (zeros of both signs, subnormals,
     huge values, infinities, NaNs) crossed with itself and on a million random pairs: hopeless => t is not NaN and t < 0.001."""
     rng = np.random.default_rng(11)
     special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1e-6, -1e-6, 0.001, -0.001, 1.0, -1.0, 3e38, -3e38, np.inf, -np.inf, np.nan], dtype=np.float32)
     num = np.concatenate([np.repeat(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
     den = np.concatenate([np.tile(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
-    finite = np.isfinite(num)
-    hopeless = (finite & (num >= 0) & (den > 0)) | (finite & (num <= 0) & (den < 0))
     with np.errstate(all="ignore"):
+        product = num * den  # binary32: may round to 0, overflow to inf, or be NaN — none of which is "hopeless"
         t = (-num) / den
+    hopeless = (product > 0) & np.isfinite(product)
     assert hopeless.sum() > 400_000
     assert not np.isnan(t[hopeless]).any()
     assert (t[hopeless] < np.float32(0.001)).all()

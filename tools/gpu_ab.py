@@ -9,8 +9,10 @@ scene, w, h, spp, reps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sy
 code = f"""
 import sys, time; sys.path.insert(0, '.')
 import numpy as np, torch
-import rt_amd
+import rt_amd, os
 from rt_amd import capi
+if '_r3' in os.environ.get('RT_HIP_LIBRARY', ''):  # a round-3 build: bind what its ABI had
+    capi.RT_HIP_SYMBOLS = [e for e in capi.RT_HIP_SYMBOLS if e[0] != 'rt_hip_live_frame_locks']
 flags = int('{os.environ.get("AB_FLAGS", "0")}')
 t = rt_amd.HipRayTracer(0)
 pod = rt_amd.Scene.named('{scene}').set_sampling({spp}).describe({w}, {h})
