@@ -3,7 +3,9 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdint>
 #include <cstring>
+#include <exception>
 
 #if (defined(__x86_64__) || defined(_M_X64)) && !defined(RT_HIP_CARRIER_PORTABLE) // (the portable path: other hosts, and the ThreadSanitizer build of the test)
 #include <emmintrin.h>
@@ -40,10 +42,22 @@ namespace rt_hip
 			const __m128i pending = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi32(a, zero), _mm_cmpeq_epi32(b, zero)), _mm_or_si128(_mm_cmpeq_epi32(c, zero), _mm_cmpeq_epi32(d, zero)));
 			if (_mm_movemask_epi8(pending) != 0)
 				return false;
-			_mm_storeu_si128(reinterpret_cast<__m128i*>(to), a);
-			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 16), b);
-			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 32), c);
-			_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 48), d);
+			if ((reinterpret_cast<uintptr_t>(to) & 15u) == 0)
+			{
+				// a 16-byte aligned destination (rt's images are 64-byte aligned, src/image.hpp:11): streaming stores — the
+				// line is written whole, nothing of it needs to be read into a cache first
+				_mm_stream_si128(reinterpret_cast<__m128i*>(to), a);
+				_mm_stream_si128(reinterpret_cast<__m128i*>(to + 16), b);
+				_mm_stream_si128(reinterpret_cast<__m128i*>(to + 32), c);
+				_mm_stream_si128(reinterpret_cast<__m128i*>(to + 48), d);
+			}
+			else
+			{
+				_mm_storeu_si128(reinterpret_cast<__m128i*>(to), a);
+				_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 16), b);
+				_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 32), c);
+				_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 48), d);
+			}
 			_mm_store_si128(reinterpret_cast<__m128i*>(from), zero);
 			_mm_store_si128(reinterpret_cast<__m128i*>(from + 16), zero);
 			_mm_store_si128(reinterpret_cast<__m128i*>(from + 32), zero);
@@ -90,8 +104,16 @@ namespace rt_hip
 	pixel_carrier::pixel_carrier(unsigned helpers)
 	{
 		threads_.reserve(helpers);
-		for (unsigned i = 0; i < helpers; i++)
-			threads_.emplace_back([this] { helper_main(); });
+		try
+		{
+			for (unsigned i = 0; i < helpers; i++)
+				threads_.emplace_back([this] { helper_main(); });
+		}
+		catch (const std::exception&)
+		{
+			// (no more threads to be had: the carrier works with however many came up — with none, the caller's thread
+			// carries the whole frame inside finish())
+		}
 	}
 
 	pixel_carrier::~pixel_carrier()
@@ -186,7 +208,12 @@ namespace rt_hip
 				std::memcpy(to_ + at, from_ + at, std::min(band_bytes_, bytes_ - at));
 			}
 			else
+			{
 				carry_band(bottom_first_ ? bands_ - 1u - claimed : claimed);
+#ifdef RT_HIP_CARRIER_SSE2
+				_mm_sfence(); // (streaming stores are weakly ordered: the band is in memory before it is reported)
+#endif
+			}
 			bands_done_.fetch_add(1, std::memory_order_release);
 		}
 	}

@@ -244,11 +244,16 @@ namespace rt_hip
 	{
 		unsigned carrier_helpers(bool several_gpus)
 		{
-			// threads besides the caller's own.  One GPU: they follow the kernel's progress (8 MB per 2.6 ms on the headline
-			// frame: one would do) and share what is left when the stream has drained — the tiles in flight at the very
-			// end.  Several GPUs, gathered: 7/8 of the frame arrives within the assemble kernel's 0.1-0.2 ms at the very
-			// end, at PCIe speed: enough threads to copy at that speed.
-			long wanted = several_gpus ? 7 : 3;
+			// threads besides the caller's own.  They follow the kernel's progress and share what is left when the stream has
+			// drained.  How many decides how SHORT a frame they can keep up with: 8.3 MB of pixels in the headline kernel's
+			// 2.6 ms is 3 GB/s (one thread would do), in config 2's 0.70 ms it is 12 GB/s, and a thread carries 4-5 GB/s (a
+			// line is read, checked, written and zeroed: 320 bytes of memory traffic per 64 bytes of pixels) — with three
+			// helpers config 2's call took + 0.08 ms over the zero-copy mode, with seven it does not.  Several GPUs,
+			// gathered: 7/8 of the frame arrives within the assemble kernel's 0.1-0.2 ms at the very end, at PCIe speed.
+			// Helpers sleep between frames; while a frame is in flight they spin, as the reference's own renderer keeps
+			// every core busy inside render() (src/renderers/mg_ray_tracer.cpp:203-204).
+			(void)several_gpus;
+			long wanted = 7;
 			if (const char* knob = std::getenv("RT_HIP_COPY_THREADS"))
 			{
 				char* end = nullptr;

@@ -76,10 +76,13 @@ namespace rt_hip
 		if (__builtin_amdgcn_ballot_w64(crosses) != 0)
 		{
 			const float num = dot(n, o) + pl.w;
-			const bool hopeless = __builtin_amdgcn_class(num * den, 0x180); // v_cmp_class_f32: bit 7 +subnormal, bit 8 +normal
+			const bool hopeless = __builtin_amdgcn_classf(num * den, 0x180); // v_cmp_class_f32: bit 7 +subnormal, bit 8 +normal
 			const bool in_reach = crosses && !hopeless;
 			if (__builtin_amdgcn_ballot_w64(in_reach) != 0)
 			{
+				// (the empty statement keeps hipcc from flattening this wave-uniform branch: everything below is selects,
+				// and it would otherwise run the division on every trip — it did, measured)
+				asm volatile("; the division of a plane test: some lane is in reach" ::: "memory");
 				const float t = divide(-num, in_reach ? den : 1.0f);
 				const bool accept = in_reach && !(t < min_hit_dist) && !(best.have && best.t <= t);
 				best.t = accept ? t : best.t;
