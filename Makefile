@@ -42,6 +42,7 @@ $(OBJDIR)/delivery.o: rt_amd/csrc/delivery.cpp rt_amd/csrc/delivery.hpp
 $(LIBDIR)/librt_hip.so: $(HIP_OBJS)
 	@mkdir -p $(LIBDIR)
 	$(HIPCC) --offload-arch=gfx950 -fPIC -shared -o $@ $(HIP_OBJS) -L/opt/rocm/lib -lrccl -lpthread
+	python3 tools/kernel_sources_hash.py > $(LIBDIR)/librt_hip.kernels.sha16   # what THIS binary's kernels were compiled from (bench.py, profiles)
 
 # test-only: the known-answer entry points of include/rt_hip_kat.h (never shipped; loads next to librt_hip.so)
 $(LIBDIR)/librt_hip_kat.so: $(OBJDIR)/kat.o $(LIBDIR)/librt_hip.so

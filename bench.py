@@ -176,9 +176,9 @@ def make_build_line(args, pod, n_gpus, single_process):
         forced = "_tiled" if args.tiled else "_streamed" if args.streamed else "_resident" if args.resident else ""
         counters_key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_n{n_gpus}{forced}" + ("_fast" if args.fast else "") + ("_tilt" if args.tilt else "")
         try:
-            from tools.kernel_sources_hash import kernel_sources_sha16
+            from tools.kernel_sources_hash import built_kernel_sources_sha16, kernel_sources_sha16
 
-            built_from = kernel_sources_sha16()
+            built_from = built_kernel_sources_sha16() or kernel_sources_sha16()  # (the hash recorded when the library was linked)
             rec = json.loads((ROOT / "profiles" / "pmc_counters.json").read_text()).get(counters_key)
         except (ImportError, OSError, ValueError):
             built_from, rec = None, None

@@ -6,11 +6,12 @@
 // presents it at once (src/window.cpp:215-216).  The kernels here store every finished pixel — one aligned 32-bit word,
 // written through to host memory — into a frame the MODULE owns; a packed pixel is never 0 (alpha is always 255,
 // src/colour.hpp:63-65,101-106), and the frame is all zero when a frame starts, so "this word is not 0" IS "this pixel is
-// finished": no flag, no counter and no change to any kernel.  The threads walk the frame in bands of 64 KB, from the bottom
-// of the image up (the order the launch hands its tiles out), copy every 64-byte line whose sixteen words are all there,
-// put zeros back behind them — the invariant the next frame starts from — and wait on a line that is not complete yet.
-// When the caller's thread has seen the stream drain it says so (finish): from then on whatever is in a line is final,
-// and what is left — the tiles that were in flight at the very end — is carried over by all threads and the caller's own.
+// finished": no flag, no counter and no change to any kernel.  The threads take the frame in bands of 64 KB, from the bottom
+// of the image up (the order the launch hands its tiles out), each keeping a few bands open and sweeping over them: every
+// 64-byte line whose sixteen words are all there is copied and zeros are put back behind it — the invariant the next frame
+// starts from — and a line that is not complete yet is left for the next sweep.  When the caller's thread has seen the
+// stream drain it says so (finish): from then on whatever is in a line is final, and what is left — the tiles that were
+// in flight at the very end — is carried over by all threads and the caller's own.
 #pragma once
 
 #include <atomic>
@@ -57,7 +58,6 @@ namespace rt_hip
 		void helper_main();
 		void post(); // make the job visible to the helpers and wake the sleeping ones
 		void work(); // what every thread does with the job in flight
-		void carry_band(size_t band);
 		void close(); // no thread may enter the job any more; waits for those inside
 
 		std::vector<std::thread> threads_;

@@ -8,7 +8,12 @@ import sys
 import time
 
 sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
-from kernel_sources_hash import kernel_sources_sha16  # noqa: E402
+from kernel_sources_hash import built_kernel_sources_sha16, kernel_sources_sha16 as _sources_sha16  # noqa: E402
+
+
+def kernel_sources_sha16():
+    """of the library that ran (recorded at link time); the sources' own hash only if that record is missing"""
+    return built_kernel_sources_sha16() or _sources_sha16()
 
 tag, raw, out, command = sys.argv[1], pathlib.Path(sys.argv[2]), pathlib.Path(sys.argv[3]), sys.argv[4]
 out.mkdir(parents=True, exist_ok=True)
