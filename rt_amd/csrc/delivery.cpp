@@ -4,8 +4,14 @@
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
+
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #if (defined(__x86_64__) || defined(_M_X64)) && !defined(RT_HIP_CARRIER_PORTABLE) // (the portable path: other hosts, and the ThreadSanitizer build of the test)
 #include <emmintrin.h>
@@ -58,10 +64,12 @@ namespace rt_hip
 				_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 32), c);
 				_mm_storeu_si128(reinterpret_cast<__m128i*>(to + 48), d);
 			}
-			_mm_store_si128(reinterpret_cast<__m128i*>(from), zero);
-			_mm_store_si128(reinterpret_cast<__m128i*>(from + 16), zero);
-			_mm_store_si128(reinterpret_cast<__m128i*>(from + 32), zero);
-			_mm_store_si128(reinterpret_cast<__m128i*>(from + 48), zero);
+			// (the zeros behind the copy are streamed too: a line left MODIFIED in this core's cache would have to be snooped
+			// out when the device stores the next frame's pixels into it)
+			_mm_stream_si128(reinterpret_cast<__m128i*>(from), zero);
+			_mm_stream_si128(reinterpret_cast<__m128i*>(from + 16), zero);
+			_mm_stream_si128(reinterpret_cast<__m128i*>(from + 32), zero);
+			_mm_stream_si128(reinterpret_cast<__m128i*>(from + 48), zero);
 			return true;
 #else
 			uint32_t words[line_bytes / 4];
@@ -101,7 +109,7 @@ namespace rt_hip
 		}
 	}
 
-	pixel_carrier::pixel_carrier(unsigned helpers)
+	pixel_carrier::pixel_carrier(unsigned helpers, int numa_node) : numa_node_(numa_node)
 	{
 		threads_.reserve(helpers);
 		try
@@ -130,8 +138,61 @@ namespace rt_hip
 			t.join();
 	}
 
+	// The helpers poll and copy memory that lives on one host node (the GPU's): they stay on that node's CPUs — those of
+	// them this process may use at all.  Best effort; RT_HIP_CARRIER_PIN=0 leaves the threads where the scheduler puts them.
+	void pixel_carrier::stay_near_the_frame()
+	{
+#if defined(__linux__)
+		if (numa_node_ < 0)
+			return;
+		if (const char* knob = std::getenv("RT_HIP_CARRIER_PIN"))
+			if (knob[0] == '0')
+				return;
+		char path[96];
+		std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", numa_node_);
+		std::FILE* f = std::fopen(path, "r");
+		if (!f)
+			return;
+		char list[4096] = {};
+		const size_t got = std::fread(list, 1, sizeof(list) - 1, f);
+		std::fclose(f);
+		list[got] = 0;
+		cpu_set_t allowed, wanted;
+		CPU_ZERO(&allowed);
+		CPU_ZERO(&wanted);
+		if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+			return;
+		int count = 0;
+		for (const char* p = list; *p;) // "0-63,128-191"
+		{
+			char* end = nullptr;
+			const long a = std::strtol(p, &end, 10);
+			if (end == p)
+				break;
+			long b = a;
+			if (*end == '-')
+			{
+				p = end + 1;
+				b = std::strtol(p, &end, 10);
+			}
+			for (long c = a; c <= b && c < CPU_SETSIZE; c++)
+				if (c >= 0 && CPU_ISSET(static_cast<int>(c), &allowed))
+				{
+					CPU_SET(static_cast<int>(c), &wanted);
+					count++;
+				}
+			if (*end != ',')
+				break;
+			p = end + 1;
+		}
+		if (count > 0)
+			(void)sched_setaffinity(0, sizeof(wanted), &wanted); // (0 = the calling THREAD)
+#endif
+	}
+
 	void pixel_carrier::helper_main()
 	{
+		stay_near_the_frame();
 		uint64_t seen = 0;
 		for (;;)
 		{
@@ -220,13 +281,19 @@ namespace rt_hip
 		{
 			size_t begin = 0, lines = 0, left = 0; // byte offset of the band, its lines (the last may be short), lines not yet taken
 			uint64_t pending[pixel_band_bytes / line_bytes / 64] = {};
+			size_t probe = 0; // the first pending line: the only one looked at until it is complete (then the band is swept)
 		} open[open_bands];
 		size_t n_open = 0;
-		bool more = true;
+		bool more = true, progress = true;
 		for (;;)
 		{
-			while (more && n_open < open_bands)
+			// One band is open at a time while it keeps yielding lines; a thread opens another (up to `open_bands`) only when a
+			// whole sweep over what it holds yielded nothing — so a narrow front of finishing tiles (the headline launch: 8
+			// bands) is followed band by band, a wide one (64 spp: 32 bands) is covered, and no thread sweeps over bands the
+			// device has not reached yet.
+			while (more && (n_open == 0 || (!progress && n_open < open_bands)))
 			{
+				progress = true; // (one more band per fruitless sweep)
 				const size_t claimed = next_band_.fetch_add(1, std::memory_order_relaxed);
 				if (claimed >= bands_)
 				{
@@ -254,10 +321,24 @@ namespace rt_hip
 				continue; // (claims what is left, to the same end, so that the counts add up)
 			}
 			const bool final_sweep = state == drained; // (loads below come after the acquire: what the device stored, all of it)
-			bool progress = false;
+			progress = false;
 			for (size_t i = 0; i < n_open;)
 			{
 				open_band& b = open[i];
+				// Poll ONE line per band.  Every line a thread keeps reading sits in its cache, and every store of the device
+				// into such a line has to be probed out of that cache first: sweeping all pending lines of the open bands all
+				// the time showed in the KERNEL's own time on long frames.  So: the band's first pending line is its probe; only
+				// when that one has arrived is the band swept for everything else that has.
+				if (!final_sweep)
+				{
+					const size_t at = b.begin + b.probe * line_bytes;
+					const size_t n = std::min(line_bytes, bytes_ - at);
+					if (!all_there(from_ + at, n))
+					{
+						i++;
+						continue;
+					}
+				}
 				for (size_t w = 0; w < sizeof(b.pending) / sizeof(b.pending[0]) && b.left; w++)
 				{
 					uint64_t bits = b.pending[w];
@@ -281,9 +362,17 @@ namespace rt_hip
 						{
 							b.pending[w] &= ~(1ull << (line & 63u));
 							b.left--;
+							progress = true;
 						}
 					}
 				}
+				if (b.left != 0) // the next probe: the first line still pending
+					for (size_t w = 0; w < sizeof(b.pending) / sizeof(b.pending[0]); w++)
+						if (b.pending[w])
+						{
+							b.probe = w * 64u + static_cast<size_t>(__builtin_ctzll(b.pending[w]));
+							break;
+						}
 				if (b.left == 0)
 				{
 #ifdef RT_HIP_CARRIER_SSE2
@@ -297,7 +386,7 @@ namespace rt_hip
 					i++;
 			}
 			if (!progress)
-				for (int k = 0; k < 16; k++)
+				for (int k = 0; k < 32; k++)
 					relax();
 		}
 	}

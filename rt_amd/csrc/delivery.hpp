@@ -27,8 +27,10 @@ namespace rt_hip
 	class pixel_carrier
 	{
 	  public:
-		// `helpers`: threads besides the caller's own (0 = the caller's thread carries everything inside finish())
-		explicit pixel_carrier(unsigned helpers);
+		// `helpers`: threads besides the caller's own (0 = the caller's thread carries everything inside finish()).
+		// `numa_node` >= 0: the helpers run on that host node's CPUs (where the frame they poll lives: a thread that polls
+		// lines of memory homed on the other socket drags every store of the device into them across the socket link).
+		explicit pixel_carrier(unsigned helpers, int numa_node = -1);
 		~pixel_carrier();
 		pixel_carrier(const pixel_carrier&) = delete;
 		pixel_carrier& operator=(const pixel_carrier&) = delete;
@@ -56,11 +58,13 @@ namespace rt_hip
 		enum : uint32_t { carry_pixels = 0, copy_bytes = 1 };
 
 		void helper_main();
+		void stay_near_the_frame(); // (the first act of a helper: its CPU affinity)
 		void post(); // make the job visible to the helpers and wake the sleeping ones
 		void work(); // what every thread does with the job in flight
 		void close(); // no thread may enter the job any more; waits for those inside
 
 		std::vector<std::thread> threads_;
+		int numa_node_ = -1;
 		std::mutex mutex_;
 		std::condition_variable wake_;
 		bool quit_ = false;					 // (under mutex_)

@@ -29,6 +29,7 @@
 // (frame_delivery), the float mean (staging_rgb), the scene image (scene_staging), the work counters.
 #include "internal.hpp"
 
+#include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -268,15 +269,63 @@ namespace rt_hip
 		}
 	}
 
-	frame_delivery::frame_delivery(unsigned helpers) : carrier(helpers) {}
+	frame_delivery::frame_delivery(unsigned helpers, int node) : numa_node(node), carrier(helpers, node) {}
+
+	hipError_t staging_frame::reserve(size_t wanted, int numa_node)
+	{
+		if (wanted <= bytes)
+			return hipSuccess;
+		release();
+		// a little slack, so that a window dragged larger pixel row by pixel row does not re-allocate every frame
+		const size_t rounded = (wanted + wanted / 8u + (2u << 20) - 1u) & ~static_cast<size_t>((2u << 20) - 1u);
+		void* const mapping = mmap(nullptr, rounded, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (mapping == MAP_FAILED)
+			return hipErrorOutOfMemory;
+#ifdef SYS_mbind
+		if (numa_node >= 0 && numa_node < 1024 && !(std::getenv("RT_HIP_NUMA_MOVE") && std::getenv("RT_HIP_NUMA_MOVE")[0] == '0'))
+		{
+			unsigned long mask[1024 / (8 * sizeof(unsigned long))] = {};
+			mask[static_cast<size_t>(numa_node) / (8 * sizeof(unsigned long))] |= 1ul << (static_cast<size_t>(numa_node) % (8 * sizeof(unsigned long)));
+			constexpr int mpol_preferred = 1;
+			(void)syscall(SYS_mbind, mapping, rounded, mpol_preferred, mask, 1024ul + 1ul, 0); // (nothing to move: no page exists yet)
+		}
+#endif
+		std::memset(mapping, 0, rounded); // first touch: the pages come into being on that node
+		const hipError_t e = hipHostRegister(mapping, rounded, hipHostRegisterMapped | hipHostRegisterPortable);
+		if (e != hipSuccess)
+		{
+			(void)munmap(mapping, rounded);
+			return e;
+		}
+		ptr = mapping;
+		bytes = rounded;
+		registered = true;
+		if (debug_frame())
+			std::fprintf(stderr, "rt_hip: the module's own frame: %zu bytes at %p on host node %d, page-locked and mapped\n", rounded, mapping, numa_node);
+		return hipSuccess;
+	}
+
+	void staging_frame::release()
+	{
+		if (ptr)
+		{
+			if (registered)
+				(void)hipHostUnregister(ptr);
+			(void)hipGetLastError();
+			(void)munmap(ptr, bytes);
+		}
+		ptr = nullptr;
+		bytes = 0;
+		registered = false;
+	}
 
 	rt_hip_status frame_delivery::begin(uint32_t* caller_pixels, size_t pixels, uint32_t** out_device_view, bool bottom_first)
 	{
 		const size_t bytes = pixels * sizeof(uint32_t);
 		if (frame.bytes < bytes)
 		{
-			RT_HIP_TRY(frame.reserve(bytes));
-			dirty = true; // (fresh page-locked memory holds anything)
+			RT_HIP_TRY(frame.reserve(bytes, numa_node));
+			dirty = false; // (a fresh frame is all zero)
 		}
 		if (dirty)
 		{
@@ -292,9 +341,10 @@ namespace rt_hip
 
 	void frame_delivery::finish()
 	{
+		const auto t0 = std::chrono::steady_clock::now();
 		carrier.finish();
 		if (debug_frame())
-			std::fprintf(stderr, "rt_hip: frame delivered: %zu of its 64 KB bands had been carried over before the stream drained\n", carrier.early_bands());
+			std::fprintf(stderr, "rt_hip: frame delivered: %zu of its 64 KB bands had been carried over before the stream drained; the rest took %.1f us\n", carrier.early_bands(), seconds_since(t0) * 1e6);
 	}
 
 	uint32_t* frame_delivery::view_on(int device)
@@ -311,7 +361,7 @@ namespace rt_hip
 	frame_delivery* delivery_of(rt_hip_ctx* ctx)
 	{
 		if (!ctx->delivery)
-			ctx->delivery.reset(new (std::nothrow) frame_delivery(carrier_helpers(ctx->multi && ctx->world > 1)));
+			ctx->delivery.reset(new (std::nothrow) frame_delivery(carrier_helpers(ctx->multi && ctx->world > 1), ctx->numa_node));
 		return ctx->delivery.get();
 	}
 }

@@ -313,13 +313,35 @@ namespace rt_hip
 	//   finish   everything the device stored is visible: the rest of the frame is carried over; returns when every pixel
 	//            is in the caller's buffer
 	//   abandon  instead of finish, on any failure: nothing further is copied, the staging frame is wiped before its next use
+	// The module-owned frame itself: anonymous memory of the module's own, placed on the host NUMA node the GPU hangs off
+	// BEFORE it is first touched, then page-locked and mapped for every device (hipHostRegister: portable).  Not hipHostMalloc:
+	// that puts the pages wherever the runtime likes; the module knows the node (sysfs), owns the memory and keeps the
+	// carrier's helper threads on that node's CPUs, so frame, pollers and GPU sit on one socket (with the helpers left to the
+	// scheduler the default mode cost the headline call + 0.02-0.03 ms and the 4K frame + 0.04-0.08 ms over the zero-copy
+	// mode; pinned, + 0.00-0.02: profiles/r04/carrier_pinning_ab.txt).
+	struct staging_frame
+	{
+		void* ptr = nullptr;
+		size_t bytes = 0;
+		bool registered = false;
+		hipError_t reserve(size_t wanted, int numa_node); // grows (contents lost: the caller wipes); ptr all zero after a successful growth
+		void release();
+		~staging_frame() { release(); }
+		template <typename T>
+		T* as() const
+		{
+			return static_cast<T*>(ptr);
+		}
+	};
+
 	struct frame_delivery
 	{
-		pinned_buffer frame; // uint32 per pixel; all zero between frames
+		staging_frame frame; // uint32 per pixel; all zero between frames
+		int numa_node = -1;	 // where the frame's pages should live
 		bool dirty = false;	 // not all zero (a failed frame): wiped by the next begin
 		pixel_carrier carrier;
 
-		explicit frame_delivery(unsigned helpers);
+		frame_delivery(unsigned helpers, int node);
 		rt_hip_status begin(uint32_t* caller_pixels, size_t pixels, uint32_t** out_device_view, bool bottom_first = true);
 		// the same frame as `device` sees it (direct frames of several GPUs); leaves that device current; NULL on failure
 		uint32_t* view_on(int device);
