@@ -111,6 +111,7 @@ namespace rt_hip
 
 	pixel_carrier::pixel_carrier(unsigned helpers, int numa_node) : numa_node_(numa_node)
 	{
+		helpers_wanted_ = helpers;
 		threads_.reserve(helpers);
 		try
 		{
@@ -185,7 +186,10 @@ namespace rt_hip
 				break;
 			p = end + 1;
 		}
-		if (count > 0)
+		// only if that leaves every helper AND the caller's thread a CPU of their own: helpers spin while a frame is in
+		// flight, and seven of them squeezed onto the three CPUs a container happens to have on that node would take
+		// turns — with the caller's thread, which the runtime has spinning on the stream — instead of working
+		if (count >= static_cast<int>(helpers_wanted_) + 2)
 			(void)sched_setaffinity(0, sizeof(wanted), &wanted); // (0 = the calling THREAD)
 #endif
 	}

@@ -65,6 +65,7 @@ namespace rt_hip
 
 		std::vector<std::thread> threads_;
 		int numa_node_ = -1;
+		unsigned helpers_wanted_ = 0;
 		std::mutex mutex_;
 		std::condition_variable wake_;
 		bool quit_ = false;					 // (under mutex_)

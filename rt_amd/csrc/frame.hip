@@ -29,6 +29,7 @@
 // (frame_delivery), the float mean (staging_rgb), the scene image (scene_staging), the work counters.
 #include "internal.hpp"
 
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/syscall.h>
 #include <unistd.h>
@@ -262,9 +263,14 @@ namespace rt_hip
 				if (end != knob && v >= 0 && v <= 32)
 					wanted = v;
 			}
-			const unsigned cores = std::thread::hardware_concurrency();
-			if (cores && static_cast<unsigned>(wanted) + 1u > cores)
-				wanted = static_cast<long>(cores) - 1;
+			// (the CPUs this PROCESS may use, not the machine's: a container's share can be a fraction of the host)
+			unsigned cores = std::thread::hardware_concurrency();
+			cpu_set_t allowed;
+			CPU_ZERO(&allowed);
+			if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) > 0)
+				cores = static_cast<unsigned>(CPU_COUNT(&allowed));
+			if (cores && static_cast<unsigned>(wanted) + 2u > cores)
+				wanted = static_cast<long>(cores) - 2; // one for the caller's thread, one for whatever else the host runs
 			return static_cast<unsigned>(std::max(wanted, 0l));
 		}
 	}
