@@ -5,7 +5,8 @@
 // calls (resize: src/window.cpp:198-203).  Two ways here:
 //
 // DEFAULT — the module's own frame.  The kernels store finished pixels (system-scope, written through) into a page-locked,
-// mapped frame that the MODULE allocated (hipHostMalloc), and a few host threads carry them on into the caller's buffer
+// mapped frame that the MODULE allocated (its own anonymous mapping, first touched on the GPU's host node and registered with
+// hipHostRegister: staging_frame below), and a few host threads carry them on into the caller's buffer
 // while the rest of the frame is still being traced (delivery.hpp).  The caller's memory is only ever touched by ordinary
 // CPU stores issued inside the call: nothing of it is registered, locked, mapped or remembered, so whatever the caller does
 // with it between two calls — free it, get the same address back, hand it to somebody else — cannot reach this module.
@@ -25,7 +26,7 @@
 // something outside this module holds a handle on caller memory AFTER rt_hip_render has returned, while a numpy caller
 // munmap()s a 8 MB frame the moment it drops it and mmap()s the next array at the same address: one of round 3's test runs
 // found a float64 array of the test itself full of packed RGBA8 words.  The module no longer takes part in that: every byte
-// the HIP runtime moves to or from host memory on its behalf lives in hipHostMalloc memory the module owns — frames
+// the HIP runtime moves to or from host memory on its behalf lives in page-locked memory the module itself allocated — frames
 // (frame_delivery), the float mean (staging_rgb), the scene image (scene_staging), the work counters.
 #include "internal.hpp"
 
