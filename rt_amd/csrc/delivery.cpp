@@ -26,7 +26,6 @@ namespace rt_hip
 		constexpr size_t pixel_band_bytes = 64u << 10; // a band of a frame in flight: 8.5 rows of a 1920-pixel frame
 		constexpr size_t copy_band_bytes = 256u << 10;
 		constexpr size_t small_frame_bytes = 128u << 10; // frames up to this size are not worth waking anybody for
-		constexpr auto stay_hot = std::chrono::microseconds(150); // a helper keeps looking for the next frame this long before it sleeps
 
 		inline void relax()
 		{
@@ -112,6 +111,13 @@ namespace rt_hip
 	pixel_carrier::pixel_carrier(unsigned helpers, int numa_node) : numa_node_(numa_node)
 	{
 		helpers_wanted_ = helpers;
+		if (const char* knob = std::getenv("RT_HIP_CARRIER_STAY_HOT_US")) // (experiments: 0 = helpers sleep between any two frames)
+		{
+			char* end = nullptr;
+			const long v = std::strtol(knob, &end, 10);
+			if (end != knob && v >= 0 && v <= 1000000)
+				stay_hot_ = std::chrono::microseconds(v);
+		}
 		threads_.reserve(helpers);
 		try
 		{
@@ -202,7 +208,7 @@ namespace rt_hip
 		{
 			// a renderer is asked for frame after frame: stay awake for a moment after each
 			bool fresh = false;
-			const auto until = std::chrono::steady_clock::now() + stay_hot;
+			const auto until = std::chrono::steady_clock::now() + stay_hot_;
 			for (unsigned spins = 0;; spins++)
 			{
 				if (posted_.load(std::memory_order_acquire) != seen)
@@ -395,7 +401,7 @@ namespace rt_hip
 		}
 	}
 
-	void pixel_carrier::begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first)
+	void pixel_carrier::begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first, bool announce_now)
 	{
 		if (in_flight_)
 			abandon();
@@ -412,6 +418,16 @@ namespace rt_hip
 		state_.store(storing, std::memory_order_relaxed);
 		early_bands_ = 0;
 		in_flight_ = true;
+		announced_ = false;
+		if (announce_now)
+			announce();
+	}
+
+	void pixel_carrier::announce()
+	{
+		if (!in_flight_ || announced_ || kind_ != carry_pixels)
+			return;
+		announced_ = true;
 		if (!threads_.empty() && bytes_ > small_frame_bytes)
 			post();
 	}

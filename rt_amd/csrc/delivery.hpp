@@ -15,6 +15,7 @@
 #pragma once
 
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstddef>
 #include <cstdint>
@@ -36,10 +37,14 @@ namespace rt_hip
 		pixel_carrier& operator=(const pixel_carrier&) = delete;
 
 		// A frame of `words` pixels begins: `from` (64-byte aligned, module-owned, ALL ZERO) is about to be stored into by
-		// the device; `to` is the caller's buffer.  Returns at once; the helpers start looking at the frame.
+		// the device; `to` is the caller's buffer.  Returns at once.
 		// `bottom_first`: the order the bands are looked at — the render launches hand their tiles out bottom row first; a frame
 		// whose bulk arrives through the multi-GPU assemble kernel fills from the top.
-		void begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first = true);
+		// `announce_now` = false: the helpers are told by announce() — the owner calls it once the launch has been issued,
+		// so that waking sleeping helpers (a futex call and a scheduler's latency each) delays no kernel.
+		void begin(uint32_t* from, uint32_t* to, size_t words, bool bottom_first = true, bool announce_now = true);
+		// The helpers start looking at the frame begun with announce_now = false.  (Never called: finish() carries everything.)
+		void announce();
 		// Everything the device stored is visible to this thread now (the stream has drained): carry over what is left.
 		// Returns when every word is in `to` and `from` is all zero again.
 		void finish();
@@ -85,5 +90,7 @@ namespace rt_hip
 		std::atomic<uint32_t> state_{ storing };
 		size_t early_bands_ = 0;
 		bool in_flight_ = false;
+		bool announced_ = false;
+		std::chrono::microseconds stay_hot_{ 150 }; // how long a helper keeps looking for the next frame before it sleeps
 	};
 }

@@ -324,6 +324,8 @@ namespace rt_hip
 		ptr = nullptr;
 		bytes = 0;
 		registered = false;
+		view = nullptr;
+		view_device = -1;
 	}
 
 	rt_hip_status frame_delivery::begin(uint32_t* caller_pixels, size_t pixels, uint32_t** out_device_view, bool bottom_first)
@@ -339,10 +341,16 @@ namespace rt_hip
 			std::memset(frame.ptr, 0, frame.bytes);
 			dirty = false;
 		}
-		void* view = nullptr;
-		RT_HIP_TRY(hipHostGetDevicePointer(&view, frame.ptr, 0));
-		*out_device_view = static_cast<uint32_t*>(view);
-		carrier.begin(frame.as<uint32_t>(), caller_pixels, pixels, bottom_first);
+		int device = -1;
+		RT_HIP_TRY(hipGetDevice(&device));
+		if (!frame.view || frame.view_device != device) // (asked once per frame buffer and device, not once per frame)
+		{
+			frame.view = nullptr;
+			RT_HIP_TRY(hipHostGetDevicePointer(&frame.view, frame.ptr, 0));
+			frame.view_device = device;
+		}
+		*out_device_view = static_cast<uint32_t*>(frame.view);
+		carrier.begin(frame.as<uint32_t>(), caller_pixels, pixels, bottom_first, false); // (announced by launched())
 		return ok();
 	}
 

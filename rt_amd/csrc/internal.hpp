@@ -324,6 +324,8 @@ namespace rt_hip
 		void* ptr = nullptr;
 		size_t bytes = 0;
 		bool registered = false;
+		int view_device = -1;	   // the device `view` is the address on (the one that was current when it was asked for)
+		void* view = nullptr;
 		hipError_t reserve(size_t wanted, int numa_node); // grows (contents lost: the caller wipes); ptr all zero after a successful growth
 		void release();
 		~staging_frame() { release(); }
@@ -342,7 +344,15 @@ namespace rt_hip
 		pixel_carrier carrier;
 
 		frame_delivery(unsigned helpers, int node);
+		// before the launch: the frame in place and all zero, its address as the current device sees it.  The carrier's threads
+		// are not told yet —
 		rt_hip_status begin(uint32_t* caller_pixels, size_t pixels, uint32_t** out_device_view, bool bottom_first = true);
+		// — but right BEHIND the launch: waking them (a futex call, and however long the host's scheduler takes) then runs
+		// beside the kernel instead of in front of it
+		void launched()
+		{
+			carrier.announce();
+		}
 		// the same frame as `device` sees it (direct frames of several GPUs); leaves that device current; NULL on failure
 		uint32_t* view_on(int device);
 		void finish();

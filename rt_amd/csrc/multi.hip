@@ -144,6 +144,8 @@ namespace rt_hip
 					if (const rt_hip_status st = render_device(member, width, height, seed, render_flags, &part, views[static_cast<size_t>(r)], nullptr, member->stream, true, keep_stats, true))
 						return st;
 				}
+				if (staged.delivery)
+					staged.delivery->launched();
 				const auto issued = std::chrono::steady_clock::now();
 				RT_HIP_TRY(hipSetDevice(root->device));
 				if (keep_stats)
@@ -206,6 +208,8 @@ namespace rt_hip
 			if (root->peer_copy && r)
 				RT_HIP_TRY(hipEventRecord(member->stripes_ready, member->stream));
 		}
+		if (staged.delivery)
+			staged.delivery->launched();
 
 		// 3. ONE gather of the compact stripe buffers to rank 0, rank order.  With root_direct the root contributes
 		//    nothing: it "sends" its own slot of the receive buffer in place, which RCCL does not copy.

@@ -415,6 +415,8 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		if (const rt_hip_status st = render_device(ctx, width, height, seed, flags & render_flag_mask, nullptr, d_frame, rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, ctx->stream, false, keep_stats, true))
 			return st;
 		// from here on the device may be storing into host memory: no return before the stream has drained
+		if (staged.delivery)
+			staged.delivery->launched();
 		hipError_t e = hipSuccess;
 		if (rgb_f32) // the float mean lands in the module's own page-locked buffer and is copied on from there
 			e = hipMemcpyAsync(ctx->staging_rgb.ptr, ctx->frame_rgb.ptr, rgb_bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -78,8 +78,12 @@ int main(int argc, char** argv)
 				for (size_t i = 0; i < words; i++)
 					to[i] = 0x000000FFu; // the caller's pre-cleared black
 				const bool bottom_first = ((round + frame) & 1) == 0;
-				carrier.begin(staging, to, words, bottom_first);
+				// the helpers are told at once, behind the "launch" (as frame_delivery does), or never (finish carries everything)
+				const unsigned told = static_cast<unsigned>((round + frame + f.tile_w) % 3);
+				carrier.begin(staging, to, words, bottom_first, told == 0);
 				std::thread device(device_stores, staging, std::cref(f), frame + 10 * round, static_cast<unsigned>(frame * 7919 + round), abandon ? (words > 64 ? 17 : 0) : ~size_t(0), bottom_first);
+				if (told == 1)
+					carrier.announce();
 				device.join(); // = the stream has drained
 				if (abandon)
 				{
