@@ -47,6 +47,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import subprocess
 import sys
@@ -54,6 +55,7 @@ import time
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent
+ROOT_CGROUP = Path("/sys/fs/cgroup")
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's host driver only supports dmabuf IPC (RCCL across processes)
 
@@ -77,13 +79,30 @@ def cpu_model() -> str:
     return "unknown CPU"
 
 
+def cpu_quota() -> float | None:
+    """CPUs' worth of time this process's cgroup grants per period (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us); None = no limit."""
+    try:
+        quota, period = (ROOT_CGROUP / "cpu.max").read_text().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float((ROOT_CGROUP / "cpu" / "cpu.cfs_quota_us").read_text())
+        period = float((ROOT_CGROUP / "cpu" / "cpu.cfs_period_us").read_text())
+        return quota / period if quota > 0 and period > 0 else None
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float) -> dict:
     """Reference-faithful CPU model (oracle, mt19937 mode) on all host cores this process may use, on a bounded
     sample: the same scene and frame size at a reduced spp chosen to take about `target_seconds`."""
     import rt_amd
     from oracle import binding as oracle  # cpu_baseline leg: the oracle is the thing timed here, by design
 
-    cores = len(os.sched_getaffinity(0))
+    allowed = len(os.sched_getaffinity(0))
+    quota = cpu_quota()  # a container's CPU-time limit: threads beyond it only take turns
+    cores = max(1, min(allowed, math.ceil(quota))) if quota else allowed
     scene = rt_amd.Scene.named(scene_name)
     spp = 1
     while True:  # grow the sample until it runs for at least half the target (thread start-up skews tiny probes)
@@ -98,8 +117,9 @@ def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float
         "unit": "Mrays/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{scene_name} {width}x{height} at {spp} spp (of the workload's spp), {stats['seconds']:.1f} s on {cores} threads of {cpu_model()}; "
-        "CPU restatement of mg_ray_tracer (thread_local mt19937, recursion, AoS scan), g++ -O3 -mavx2 -mfma -ffast-math -ffp-contract=fast "
+        "sample": f"{scene_name} {width}x{height} at {spp} spp (of the workload's spp), {stats['seconds']:.1f} s on {cores} threads of {cpu_model()} "
+        + (f"(the process may run on {allowed} CPUs but its cgroup grants the CPU time of {quota:g}: one thread per granted CPU); " if quota and cores < allowed else "(every CPU the process may run on); ")
+        + "CPU restatement of mg_ray_tracer (thread_local mt19937, recursion, AoS scan), g++ -O3 -mavx2 -mfma -ffast-math -ffp-contract=fast "
         "(-march=native is not used: the .so is built on another host)",
     }
 

@@ -20,6 +20,32 @@ def test_algorithmic_flops_formula():
     assert bench.algorithmic_flops(1, 1, 100000, 2) == 70 + (2200000 + 32 + 60)
 
 
+def test_cpu_baseline_counts_the_cpus_the_container_is_granted(tmp_path, monkeypatch):
+    """`cpu_baseline.cores` is what the timed leg could really use: a GPU box shows 256 CPUs to a process whose cgroup grants
+    it the time of 16 (cpu.max "1600000 100000") — 256 threads there take turns on 16 CPUs' worth of time."""
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    monkeypatch.setattr(bench, "ROOT_CGROUP", tmp_path)
+    assert bench.cpu_quota() is None  # no controller files at all
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert bench.cpu_quota() == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert bench.cpu_quota() is None
+    (tmp_path / "cpu.max").unlink()
+    (tmp_path / "cpu").mkdir()
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("250000\n")
+    (tmp_path / "cpu" / "cpu.cfs_period_us").write_text("100000\n")
+    assert bench.cpu_quota() == 2.5
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("-1\n")
+    assert bench.cpu_quota() is None
+    # the leg itself, with the time of two CPUs granted: two threads, and the line says why
+    (tmp_path / "cpu" / "cpu.cfs_quota_us").write_text("200000\n")
+    if len(os.sched_getaffinity(0)) > 2:
+        leg = bench.cpu_baseline("basic", 64, 36, 0.2)
+        assert leg["cores"] == 2 and "grants the CPU time of 2" in leg["sample"] and leg["kind"] == "port" and leg["value"] > 0
+
+
 def run_bench(args, launcher=None, timeout=600, expect_rc=0):
     cmd = (launcher or [sys.executable]) + [str(ROOT / "bench.py")] + args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
