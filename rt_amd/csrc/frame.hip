@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <new>
 
 using namespace rt_hip;
@@ -245,6 +246,36 @@ namespace rt_hip
 	// ---- the module's own frame --------------------------------------------------------------------------------------------
 	namespace
 	{
+		// CPUs' worth of time per period the process's cgroup grants it (v2: cpu.max, v1: cpu.cfs_quota_us / cpu.cfs_period_us);
+		// 0 = no limit, or none that can be read
+		double granted_cpu_time()
+		{
+			if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r"))
+			{
+				char quota[32] = {};
+				double period = 0.0;
+				const int got = std::fscanf(f, "%31s %lf", quota, &period);
+				std::fclose(f);
+				if (got == 2 && period > 0.0 && quota[0] >= '0' && quota[0] <= '9')
+					return std::strtod(quota, nullptr) / period;
+				return 0.0; // ("max": no limit)
+			}
+			double quota = 0.0, period = 0.0;
+			if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))
+			{
+				if (std::fscanf(f, "%lf", &quota) != 1)
+					quota = 0.0;
+				std::fclose(f);
+			}
+			if (FILE* f = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))
+			{
+				if (std::fscanf(f, "%lf", &period) != 1)
+					period = 0.0;
+				std::fclose(f);
+			}
+			return quota > 0.0 && period > 0.0 ? quota / period : 0.0;
+		}
+
 		unsigned carrier_helpers(bool several_gpus)
 		{
 			// threads besides the caller's own.  They follow the kernel's progress and share what is left when the stream has
@@ -264,12 +295,17 @@ namespace rt_hip
 				if (end != knob && v >= 0 && v <= 32)
 					wanted = v;
 			}
-			// (the CPUs this PROCESS may use, not the machine's: a container's share can be a fraction of the host)
+			// (the CPUs this PROCESS may use, not the machine's: a container's share can be a fraction of the host — by the set
+			// of CPUs it may run on, or by the CPU TIME its cgroup grants: a GPU box of the pool this was measured on shows
+			// all 256 hardware threads to a job that is granted the time of 16, cpu.max = "1600000 100000")
 			unsigned cores = std::thread::hardware_concurrency();
 			cpu_set_t allowed;
 			CPU_ZERO(&allowed);
 			if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0 && CPU_COUNT(&allowed) > 0)
 				cores = static_cast<unsigned>(CPU_COUNT(&allowed));
+			const double granted = granted_cpu_time();
+			if (granted > 0.0 && granted < static_cast<double>(cores))
+				cores = static_cast<unsigned>(std::max(1.0, std::ceil(granted)));
 			if (cores && static_cast<unsigned>(wanted) + 2u > cores)
 				wanted = static_cast<long>(cores) - 2; // one for the caller's thread, one for whatever else the host runs
 			return static_cast<unsigned>(std::max(wanted, 0l));
@@ -376,7 +412,11 @@ namespace rt_hip
 	frame_delivery* delivery_of(rt_hip_ctx* ctx)
 	{
 		if (!ctx->delivery)
+		{
 			ctx->delivery.reset(new (std::nothrow) frame_delivery(carrier_helpers(ctx->multi && ctx->world > 1), ctx->numa_node));
+			if (ctx->delivery && debug_frame())
+				std::fprintf(stderr, "rt_hip: device %d: %u helper threads carry frames to the caller's buffer (the cgroup grants the time of %.1f CPUs; 0 = no limit)\n", ctx->device, ctx->delivery->carrier.helpers(), granted_cpu_time());
+		}
 		return ctx->delivery.get();
 	}
 }
