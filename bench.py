@@ -171,6 +171,33 @@ def parse_args():
     return ap.parse_args()
 
 
+# What one wave64 vector instruction costs a SIMD when it sits among plain FMAs, eight waves per SIMD — measured with
+# tools/valu_rate_probe2 (profiles/r04/valu_issue_costs.txt), in shader cycles.  `int32` and `other` are blends over what the
+# render loops hold of each (integer multiply 3.5, SDWA 5.1, add / shift / xor 2.2-2.6; compare and select 2.6-2.8, move 2.2).
+VALU_CLASS_CYCLES = {"fma_f32": 2.22, "mul_f32": 2.22, "add_f32": 2.22, "trans_f32": 10.6, "cvt": 2.2, "int32": 2.8, "int64": 5.1, "other": 2.6}
+
+
+def issue_by_class(c: dict, duration_ms: float, simds: int) -> dict | None:
+    """roofline.issue.by_class: the launch's vector instructions by class (SQ_INSTS_VALU_* of a PMC pass) priced at what each
+    class was MEASURED to cost, against the kernel's time: the ceiling of this instruction mix, not of a stream of FMAs."""
+    names = {"fma_f32": "SQ_INSTS_VALU_FMA_F32", "mul_f32": "SQ_INSTS_VALU_MUL_F32", "add_f32": "SQ_INSTS_VALU_ADD_F32", "trans_f32": "SQ_INSTS_VALU_TRANS_F32",
+             "cvt": "SQ_INSTS_VALU_CVT", "int32": "SQ_INSTS_VALU_INT32", "int64": "SQ_INSTS_VALU_INT64"}
+    if any(c.get(v) is None for v in names.values()) or not c.get("SQ_INSTS_VALU"):
+        return None
+    counts = {k: c[v] for k, v in names.items()}
+    counts["other"] = max(c["SQ_INSTS_VALU"] - sum(counts.values()), 0.0)  # compares, selects, moves, lane reads: no counter of their own
+    cycles = sum(counts[k] * VALU_CLASS_CYCLES[k] for k in counts)
+    ms = cycles / (simds * SHADER_CLOCK_HZ) * 1e3
+    return {
+        "share_of_valu_insts": {k: round(v / c["SQ_INSTS_VALU"], 4) for k, v in counts.items()},
+        "cycles_per_inst_measured": VALU_CLASS_CYCLES,
+        "issue_time_ms": round(ms, 4),
+        "frac_of_kernel_time": round(ms / duration_ms, 4),
+        "what": "every class's wave-instructions x the cycles one such instruction was measured to cost a SIMD among plain FMAs at 8 waves per SIMD (tools/valu_rate_probe2, profiles/r04/valu_issue_costs.txt), "
+                "/ (1024 SIMDs x 2.4 GHz): the time this launch's vector stream needs to ISSUE, whatever else the kernel does",
+    }
+
+
 def make_build_line(args, pod, n_gpus, single_process):
     """The contract line for one measured form (closure over the workload)."""
     import rt_amd
@@ -226,6 +253,7 @@ def make_build_line(args, pod, n_gpus, single_process):
                     "what": "VALU wave-instructions of one launch (SQ_INSTS_VALU) x 2 cycles / (1024 SIMDs x 2.4 GHz) over this run's kernel time: how close the kernel's OWN instruction stream runs to the vector issue rate — the flop fraction above also counts against it every instruction that is not an FMA (integer hashing of the random streams, lane-mode selects, quarter-rate rsq / rcp / sqrt)",
                     "source": f"{rec.get('source')} ({rec.get('measured')}, kernel sources {rec.get('kernel_sources_sha16')}); kernel time from this run",
                 }
+                issue["by_class"] = issue_by_class(c, duration_ms, simds)
         roofline = {
             "bound": "valu_fp32",
             "kernel": f"render_{member['kernel']}",

@@ -20,6 +20,29 @@ def test_algorithmic_flops_formula():
     assert bench.algorithmic_flops(1, 1, 100000, 2) == 70 + (2200000 + 32 + 60)
 
 
+def test_issue_by_class_prices_every_instruction_once():
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    counters = {"SQ_INSTS_VALU": 1000.0, "SQ_INSTS_VALU_FMA_F32": 400.0, "SQ_INSTS_VALU_MUL_F32": 100.0, "SQ_INSTS_VALU_ADD_F32": 100.0, "SQ_INSTS_VALU_TRANS_F32": 20.0,
+                "SQ_INSTS_VALU_CVT": 10.0, "SQ_INSTS_VALU_INT32": 150.0, "SQ_INSTS_VALU_INT64": 20.0}
+    got = bench.issue_by_class(counters, 1.0, 1024)
+    assert abs(sum(got["share_of_valu_insts"].values()) - 1.0) < 1e-3 and got["share_of_valu_insts"]["other"] == 0.2
+    cost = bench.VALU_CLASS_CYCLES
+    cycles = 600 * cost["fma_f32"] + 20 * cost["trans_f32"] + 10 * cost["cvt"] + 150 * cost["int32"] + 20 * cost["int64"] + 200 * cost["other"]
+    assert abs(got["issue_time_ms"] - cycles / (1024 * bench.SHADER_CLOCK_HZ) * 1e3) < 1e-4  # (the line rounds to 0.1 us)
+    assert bench.issue_by_class({"SQ_INSTS_VALU": 1000.0}, 1.0, 1024) is None  # an entry without the class passes: no figure
+    # the committed figures: every entry that has the class counters prices to less than its kernel's own time
+    table = json.loads((ROOT / "profiles" / "pmc_counters.json").read_text())
+    priced = 0
+    for key, rec in table.items():
+        by_class = bench.issue_by_class(rec["counters_per_launch"], rec["kernel_ms_traced_mean_of_timed_steps"], 1024)
+        if by_class:
+            priced += 1
+            assert 0.5 < by_class["frac_of_kernel_time"] <= 1.0, (key, by_class)
+    assert priced >= 2
+
+
 def test_cpu_baseline_counts_the_cpus_the_container_is_granted(tmp_path, monkeypatch):
     """`cpu_baseline.cores` is what the timed leg could really use: a GPU box shows 256 CPUs to a process whose cgroup grants
     it the time of 16 (cpu.max "1600000 100000") — 256 threads there take turns on 16 CPUs' worth of time."""
