@@ -507,6 +507,20 @@ def test_headline_basic_1080p_256spp(tracer):
     check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(256), 1920, 1080, seed=1, oracle_world=32)
 
 
+@pytest.mark.parametrize("name,tilted", [("basic_plane", False), ("dielectric_plane", False), ("basic_plane", True)])
+def test_the_reference_scenes_with_their_plane_at_full_size(tracer, name, tilted):
+    """scenes/basic.toml and scenes/dielectric.toml of the reference with the ground plane they carry one comment away, at the
+    headline's size and sample count — through the scalar-register kernel's plane builds (round 4), the third case through
+    its general-camera build (a camera that is not axis-aligned: w varies over the frame)."""
+    scene = rt_amd.Scene.named(name).set_sampling(256)
+    if tilted:
+        scene.set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+        ivp = scene.describe(1920, 1080).inverse_view_projection[:]
+        assert not (ivp[12] == 0.0 and ivp[13] == 0.0)
+    stats = check_full_size(tracer, scene, 1920, 1080, seed=1, oracle_world=32)
+    assert stats["kernel"] == "small" and stats["plane_tests"] == stats["segments"]
+
+
 def test_config4_basic_4k_tile_split(tracer):
     """BASELINE config 4's frame (3840x2160), every rank's part of the 8-way split assembled on the device; at the full
     256 spp when the host can render the oracle frame in seconds (2.1 G samples), at 8 spp otherwise."""
