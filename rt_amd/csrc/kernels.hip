@@ -58,6 +58,13 @@
 #ifndef RT_HIP_WAVES_MANY
 #define RT_HIP_WAVES_MANY 7 // small kernel with 5..8 spheres
 #endif
+// small kernel with seven spheres and a plane (dielectric.toml with the plane it carries one comment away): the plane test's
+// division on top of seven spheres spills at 72 registers in the loop's hottest stretch — 3.99 ms at 7 waves per SIMD, 3.59 at 6.
+// Nothing else wants 6: eight spheres and seven primitives of any kind prefer 7 by 2.5-3 %, 6 + 2 by 1 %, 5 + 3 does not care
+// (profiles/r04/waves_full_ab.txt)
+#ifndef RT_HIP_WAVES_SEVEN_AND_PLANE
+#define RT_HIP_WAVES_SEVEN_AND_PLANE 6
+#endif
 #ifndef RT_HIP_WAVES_RESIDENT
 #define RT_HIP_WAVES_RESIDENT 7
 #endif
@@ -423,7 +430,7 @@ namespace rt_hip
 		// LDS-resident kernel (+35 % on basic.toml); now they keep the scalar-register kernel, in a build of it that carries
 		// the 18 scalars of the general form INSTEAD of the 18 of the affine one (both would not fit its scalar registers).
 		template <int NS, bool SM, bool HALF = false, int NP = 0, bool GC = false>
-		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS == 7 && NP == 1 ? RT_HIP_WAVES_SEVEN_AND_PLANE : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW)))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,

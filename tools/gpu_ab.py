@@ -1,6 +1,6 @@
 """A/B timing of builds of librt_hip.so, one process per build, interleaved over two rounds:
 
-    python tools/gpu_ab.py <scene> <W> <H> <spp> <reps> [lib.so ...]      (libs under rt_amd/lib/)
+    python tools/gpu_ab.py <scene name | file.toml> <W> <H> <spp> <reps> [lib.so ...]      (libs under rt_amd/lib/)
 
 Per build: the kernel alone (scene resident, frame in HBM: rt_hip_stats.render_ms) and the drop-in call (host scene in,
 frame in a page-locked host back buffer out: wall clock and the kernel inside it).  min / median over <reps> frames."""
@@ -15,7 +15,7 @@ if '_r3' in os.environ.get('RT_HIP_LIBRARY', ''):  # a round-3 build: bind what 
     capi.RT_HIP_SYMBOLS = [e for e in capi.RT_HIP_SYMBOLS if e[0] != 'rt_hip_live_frame_locks']
 flags = int('{os.environ.get("AB_FLAGS", "0")}')
 t = rt_amd.HipRayTracer(0)
-pod = rt_amd.Scene.named('{scene}').set_sampling({spp}).describe({w}, {h})
+pod = (rt_amd.Scene.load('{scene}') if '{scene}'.endswith('.toml') else rt_amd.Scene.named('{scene}')).set_sampling({spp}).describe({w}, {h})
 t.upload(pod)
 frame = torch.empty(({h}, {w}), dtype=torch.int32, device='cuda:0')
 s = torch.cuda.current_stream().cuda_stream
