@@ -78,6 +78,27 @@ def lib() -> C.CDLL:
     return _lib
 
 
+def default_threads() -> int:
+    """threads = 0 means "all the host gives": the CPUs this process may run on, capped by the CPU TIME its cgroup grants (a GPU
+    box shows 256 CPUs to a job that is granted the time of 16 — 256 threads there only take turns)."""
+    import math
+    import os
+
+    allowed = len(os.sched_getaffinity(0))
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None), ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                quota, period = open(quota_file).read().split()[:2]
+            else:
+                quota, period = open(quota_file).read().strip(), open(period_file).read().strip()
+            if quota != "max" and float(quota) > 0 and float(period) > 0:
+                return max(1, min(allowed, math.ceil(float(quota) / float(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return allowed
+
+
 def _local_rows(height, rank, world, stripe):
     return sum(1 for y in range(height) if (y // stripe) % world == rank)
 
@@ -89,7 +110,7 @@ def render(scene: RtHipScene, width: int, height: int, seed: int = 1, trace_orde
     rgb = np.zeros((rows, width, 3), dtype=np.float32) if want_rgb else None
     stats = OracleStats()
     part = C.byref(RtHipPartition(*partition)) if partition is not None else None
-    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order | (MATERIALS_SM if sm_materials else 0) | (PREVIEW if preview else 0), part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    rc = lib().oracle_render(C.byref(scene), width, height, seed, trace_order | (MATERIALS_SM if sm_materials else 0) | (PREVIEW if preview else 0), part, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads or default_threads(), C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"oracle_render failed ({rc})")
     return rgba, rgb, stats.as_dict()
@@ -99,7 +120,7 @@ def render_mt19937(scene: RtHipScene, width: int, height: int, fixed_seed: int =
     rgba = np.zeros((height, width), dtype=np.uint32)
     rgb = np.zeros((height, width, 3), dtype=np.float32) if want_rgb else None
     stats = OracleStats()
-    rc = lib().oracle_render_mt19937(C.byref(scene), width, height, fixed_seed, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads, C.byref(stats))
+    rc = lib().oracle_render_mt19937(C.byref(scene), width, height, fixed_seed, rgba.ctypes.data, rgb.ctypes.data if rgb is not None else None, threads or default_threads(), C.byref(stats))
     if rc != 0:
         raise RuntimeError(f"oracle_render_mt19937 failed ({rc})")
     return rgba, rgb, stats.as_dict()
