@@ -1,0 +1,185 @@
+"""A SECOND restatement of the path, independent of oracle/cpu_ref.cpp: numpy, binary64, vectorised over all samples of a frame,
+written from the reference's text — worker lambda and trace (src/renderers/mg_ray_tracer.cpp:155-201), test_planes / test_spheres
+/ select (:36-102), lambert_scatter / metal_scatter (:110-140), screen_to_world (src/camera.hpp:42-48) — and from the stream
+contract (the numpy generator of tests/test_oracle_kat.py, itself independent of the oracle's C++).
+
+The oracle is unpinned (the reference has no tests and cannot be built here): the only tie between it and the reference is
+one reading of the source.  This file is a second coding of that reading in another language, another precision and another
+program structure (no recursion, no per-pixel loop, no float32 rounding anywhere), fed the SAME random numbers.  The two must
+agree on every pixel to within what float32 rounding and the odd sample that falls on the other side of a silhouette can do."""
+import numpy as np
+import pytest
+
+import rt_amd
+from oracle import binding as oracle
+from tests.test_oracle_kat import M32, _stream_start
+
+MIN_HIT_DIST = 0.001  # mg_ray_tracer.cpp:20
+APPROX_ZERO = 1.0e-6  # muu's default epsilon for float (vector::approx_zero)
+METAL = 1  # material_type::metal, src/common.hpp:105-115
+
+
+def column(pointer, n, dtype=np.float64):
+    return np.array([pointer[i] for i in range(n)], dtype=dtype)
+
+
+class Streams:
+    """one random stream per (pixel, sample): contract v2, numpy (tests/test_oracle_kat.py::_draws, one draw at a time)"""
+
+    def __init__(self, seed, pixels, samples):
+        self.key, self.stride, self.counter = _stream_start(seed, pixels, samples)
+
+    def next(self, lanes):
+        c = (self.counter[lanes] + self.stride[lanes]) & M32
+        self.counter[lanes] = c
+        x = c ^ (c >> np.uint64(16))
+        x = (x * np.uint64(0x7FEB352D) + self.key[lanes]) & M32
+        x ^= x >> np.uint64(15)
+        x = (x * np.uint64(0x846CA68B)) & M32
+        return (x >> np.uint64(8)).astype(np.float64) * 2.0**-24
+
+    def unit_vector(self, lanes):
+        """random_unit_vector(), src/random.hpp:57-66: x, y, z in [0, 1), normalised (all zero: 2^-72, not handled here)"""
+        v = np.stack([self.next(lanes), self.next(lanes), self.next(lanes)], axis=-1)
+        return v / np.linalg.norm(v, axis=-1, keepdims=True)
+
+
+def render_f64(pod, width, height, seed):
+    """float64 mean colour per pixel, [height, width, 3]"""
+    spp, max_bounces = pod.samples_per_pixel, pod.max_bounces
+    centres = np.stack([column(pod.sphere_center_x, pod.n_spheres), column(pod.sphere_center_y, pod.n_spheres), column(pod.sphere_center_z, pod.n_spheres)], axis=-1)
+    radii = column(pod.sphere_radius, pod.n_spheres)
+    sphere_material = column(pod.sphere_material, pod.n_spheres, np.int64)
+    plane_n = np.stack([column(pod.plane_normal_x, pod.n_planes), column(pod.plane_normal_y, pod.n_planes), column(pod.plane_normal_z, pod.n_planes)], axis=-1)
+    plane_d = column(pod.plane_d, pod.n_planes)
+    plane_material = column(pod.plane_material, pod.n_planes, np.int64)
+    kind = column(pod.material_type, pod.n_materials, np.int64)
+    albedo = column(pod.material_albedo, 4 * pod.n_materials).reshape(-1, 4)[:, :3]  # rt::colour: r, g, b, a per material (src/colour.hpp:17-57)
+    attenuation_of = albedo * column(pod.material_reflectivity, pod.n_materials)[:, None]  # :115,131
+    roughness = column(pod.material_roughness, pod.n_materials)
+    inverse_vp = np.array(list(pod.inverse_view_projection), dtype=np.float64).reshape(4, 4)
+
+    ys, xs, ss = np.meshgrid(np.arange(height), np.arange(width), np.arange(spp), indexing="ij")
+    xs, ys, ss = xs.ravel(), ys.ravel(), ss.ravel()
+    n = xs.size
+    streams = Streams(seed, (ys * width + xs).astype(np.uint32), ss.astype(np.uint32))
+    everyone = np.arange(n)
+    # `pos = screen_pos + (i ? random<vec2>() : vec2{0.5})` (:189): x drawn first; sample 0 draws nothing here
+    later = everyone[ss > 0]
+    jitter_x, jitter_y = np.full(n, 0.5), np.full(n, 0.5)
+    jitter_x[later] = streams.next(later)
+    jitter_y[later] = streams.next(later)
+    px, py = xs + jitter_x, ys + jitter_y
+
+    def screen_to_world(depth):  # camera.hpp:42-48
+        ndc = np.stack([2.0 * px / width - 1.0, -2.0 * py / height + 1.0, np.full(n, depth), np.ones(n)], axis=-1)
+        world = ndc @ inverse_vp.T
+        return world[:, :3] / world[:, 3:4]
+
+    near, far = screen_to_world(0.0), screen_to_world(1.0)
+    origin = near
+    direction = far - near
+    direction /= np.linalg.norm(direction, axis=-1, keepdims=True)  # vec3::direction(near, far) (:193)
+
+    throughput = np.ones((n, 3))
+    result = np.zeros((n, 3))
+    alive = everyone
+    for _ in range(max_bounces):  # `if (!(max_bounces--)) return {}` (:157): a path that is still alive after the loop is black
+        if alive.size == 0:
+            break
+        o, d = origin[alive], direction[alive]
+        # test_planes (:36-60): the first plane at the smallest distance >= min_hit_dist
+        best_plane_t = np.full(alive.size, np.inf)
+        best_plane = np.full(alive.size, -1)
+        for i in range(pod.n_planes):
+            den = d @ plane_n[i]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = -(o @ plane_n[i] + plane_d[i]) / den
+            ok = (np.abs(den) > APPROX_ZERO) & (t >= 0.0) & (t >= MIN_HIT_DIST) & ~(t >= best_plane_t)  # `hit_dist <= *hit` keeps the earlier one
+            best_plane_t = np.where(ok, t, best_plane_t)
+            best_plane = np.where(ok, i, best_plane)
+        # test_spheres (:62-87)
+        best_sphere_t = np.full(alive.size, np.inf)
+        best_sphere = np.full(alive.size, -1)
+        for i in range(pod.n_spheres):
+            e = centres[i] - o
+            a = np.einsum("ij,ij->i", e, d)
+            e2 = np.einsum("ij,ij->i", e, e)
+            disc = radii[i] ** 2 - (e2 - a * a)
+            f = np.sqrt(np.maximum(disc, 0.0))
+            t = np.where(e2 < radii[i] ** 2, a + f, a - f)  # from inside: the far root
+            ok = (disc >= 0.0) & (t >= 0.0) & (t >= MIN_HIT_DIST) & ~(t >= best_sphere_t)
+            best_sphere_t = np.where(ok, t, best_sphere_t)
+            best_sphere = np.where(ok, i, best_sphere)
+        # select(test_spheres, test_planes) (:96-102,160-161): the sphere unless the plane is strictly nearer
+        sphere_wins = (best_sphere >= 0) & ((best_plane < 0) | (best_sphere_t <= best_plane_t))
+        plane_wins = (best_plane >= 0) & ~sphere_wins
+        hit = sphere_wins | plane_wins
+        # miss: the sky (:163-164)
+        missed = alive[~hit]
+        t_sky = 0.5 * (direction[missed, 1] + 1.0)
+        result[missed] = throughput[missed] * ((1.0 - t_sky)[:, None] * np.array([1.0, 1.0, 1.0]) + t_sky[:, None] * np.array([0.5, 0.7, 1.0]))
+        # hit: position, normal, material
+        lanes = alive[hit]
+        if lanes.size == 0:
+            alive = lanes
+            break
+        distance = np.where(sphere_wins, best_sphere_t, best_plane_t)[hit]
+        position = origin[lanes] + direction[lanes] * distance[:, None]  # r.at(hit.distance)
+        is_sphere = sphere_wins[hit]
+        sphere_index = np.maximum(best_sphere[hit], 0)
+        plane_index = np.maximum(best_plane[hit], 0)
+        outward = position - (centres[sphere_index] if pod.n_spheres else np.zeros((lanes.size, 3)))
+        outward /= np.maximum(np.linalg.norm(outward, axis=-1, keepdims=True), 1e-300)  # vec3::direction(center, r.at(t)) (:85)
+        normal = np.where(is_sphere[:, None], outward, plane_n[plane_index] if pod.n_planes else outward)
+        material = np.where(is_sphere, sphere_material[sphere_index] if pod.n_spheres else 0, plane_material[plane_index] if pod.n_planes else 0)
+        unit = streams.unit_vector(lanes)
+        metal = kind[material] == METAL  # every other kind shades as lambert (:142-152)
+        # lambert_scatter (:110-123)
+        lambert = normal + unit
+        tiny = np.all(np.abs(lambert) <= APPROX_ZERO, axis=-1)
+        lambert = np.where(tiny[:, None], normal, lambert)
+        # metal_scatter (:126-140); reflect(v, n) = v - 2 dot(v, n) n (src/common.hpp:100-103)
+        v = direction[lanes] / np.linalg.norm(direction[lanes], axis=-1, keepdims=True)
+        reflected = v - 2.0 * np.einsum("ij,ij->i", v, normal)[:, None] * normal
+        shiny = reflected + roughness[material][:, None] * unit
+        absorbed = metal & (np.einsum("ij,ij->i", shiny, normal) <= 0.0)  # `return {}`: the sample is black
+        scatter = np.where(metal[:, None], shiny, lambert)
+        scatter /= np.linalg.norm(scatter, axis=-1, keepdims=True)
+        throughput[lanes] = throughput[lanes] * attenuation_of[material]
+        origin[lanes] = position
+        direction[lanes] = scatter
+        alive = lanes[~absorbed]
+    # `colour /= samples_per_pixel` (:195)
+    return result.reshape(height, width, spp, 3).mean(axis=2)
+
+
+CASES = [
+    ("basic", None, 96, 54, 24, 10),
+    ("dielectric", None, 96, 54, 16, 10),  # mg semantics: every kind but metal shades as lambert, albedo x reflectivity > 1 included
+    ("basic_plane", None, 80, 45, 16, 6),
+    ("dielectric_plane", ((0.2, 1.2, 7.0), (0.0, -0.15, -1.0)), 80, 45, 16, 10),  # a camera that is not axis-aligned
+]
+
+
+@pytest.mark.parametrize("name,camera,width,height,spp,bounces", CASES)
+def test_the_oracle_agrees_with_an_independent_float64_restatement(name, camera, width, height, spp, bounces):
+    scene = rt_amd.Scene.named(name).set_sampling(spp, bounces)
+    if camera:
+        scene.set_camera(*camera)
+    pod = scene.describe(width, height)
+    seed = 12345
+    _, oracle_mean, stats = oracle.render(pod, width, height, seed=seed)
+    mine = render_f64(pod, width, height, seed)
+    difference = np.abs(oracle_mean.astype(np.float64) - mine).max(axis=-1)
+    # A sample that lands on the other side of a silhouette, of the min_hit_dist threshold or of the metal's absorption test
+    # under float32 rounding changes a pixel's mean by up to (its weight)/spp — and everything downstream of it; such pixels
+    # are rare.  Everywhere else the two agree to float32 rounding accumulated over a path.
+    scale = max(1.0, float(mine.max()))
+    assert (difference <= 2e-4 * scale).mean() >= 0.995, (name, (difference <= 2e-4 * scale).mean(), np.sort(difference.ravel())[-10:])
+    assert (difference <= 1e-5 * scale).mean() >= 0.98, (name, (difference <= 1e-5 * scale).mean())
+    assert np.median(difference) <= 1e-6 * scale, (name, np.median(difference))  # (measured: 3e-8 .. 4e-8)
+    # the frame as a whole: the mean colour, to 5e-5 relative (measured: 1e-6 .. 7e-6) — a systematic difference (a wrong factor,
+    # a wrong draw order, a wrong tie rule, a wrong column layout) shows here at once
+    assert np.allclose(oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)), rtol=5e-5), (oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)))
+    assert stats["primary_samples"] == width * height * spp
