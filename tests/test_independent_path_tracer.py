@@ -17,6 +17,7 @@ from tests.test_oracle_kat import M32, _stream_start
 MIN_HIT_DIST = 0.001  # mg_ray_tracer.cpp:20
 APPROX_ZERO = 1.0e-6  # muu's default epsilon for float (vector::approx_zero)
 METAL = 1  # material_type::metal, src/common.hpp:105-115
+REFRACTING = (2, 3, 4, 5, 6)  # dielectric, air, vacuum, water, ice: sm_ray_tracer.cpp:229-233
 
 
 def column(pointer, n, dtype=np.float64):
@@ -44,7 +45,7 @@ class Streams:
         return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
-def render_f64(pod, width, height, seed):
+def render_f64(pod, width, height, seed, sm_materials=False):
     """float64 mean colour per pixel, [height, width, 3]"""
     spp, max_bounces = pod.samples_per_pixel, pod.max_bounces
     centres = np.stack([column(pod.sphere_center_x, pod.n_spheres), column(pod.sphere_center_y, pod.n_spheres), column(pod.sphere_center_z, pod.n_spheres)], axis=-1)
@@ -57,6 +58,7 @@ def render_f64(pod, width, height, seed):
     albedo = column(pod.material_albedo, 4 * pod.n_materials).reshape(-1, 4)[:, :3]  # rt::colour: r, g, b, a per material (src/colour.hpp:17-57)
     attenuation_of = albedo * column(pod.material_reflectivity, pod.n_materials)[:, None]  # :115,131
     roughness = column(pod.material_roughness, pod.n_materials)
+    reflectivity = column(pod.material_reflectivity, pod.n_materials)
     inverse_vp = np.array(list(pod.inverse_view_projection), dtype=np.float64).reshape(4, 4)
 
     ys, xs, ss = np.meshgrid(np.arange(height), np.arange(width), np.arange(spp), indexing="ij")
@@ -133,19 +135,46 @@ def render_f64(pod, width, height, seed):
         outward /= np.maximum(np.linalg.norm(outward, axis=-1, keepdims=True), 1e-300)  # vec3::direction(center, r.at(t)) (:85)
         normal = np.where(is_sphere[:, None], outward, plane_n[plane_index] if pod.n_planes else outward)
         material = np.where(is_sphere, sphere_material[sphere_index] if pod.n_spheres else 0, plane_material[plane_index] if pod.n_planes else 0)
-        unit = streams.unit_vector(lanes)
-        metal = kind[material] == METAL  # every other kind shades as lambert (:142-152)
+        # which scatter function (mg: :142-152 — metal, everything else lambert; sm: sm_ray_tracer.cpp:221-236 — dielectric, air,
+        # vacuum, water and ice refract as well)
+        metal = kind[material] == METAL
+        refracts = np.isin(kind[material], REFRACTING) if sm_materials else np.zeros(lanes.size, dtype=bool)
+        diffuse = ~refracts
+        unit = np.zeros((lanes.size, 3))
+        unit[diffuse] = streams.unit_vector(lanes[diffuse])  # lambert and metal draw a unit vector, dielectric_scatter ONE number
         # lambert_scatter (:110-123)
         lambert = normal + unit
         tiny = np.all(np.abs(lambert) <= APPROX_ZERO, axis=-1)
         lambert = np.where(tiny[:, None], normal, lambert)
         # metal_scatter (:126-140); reflect(v, n) = v - 2 dot(v, n) n (src/common.hpp:100-103)
-        v = direction[lanes] / np.linalg.norm(direction[lanes], axis=-1, keepdims=True)
+        incoming = direction[lanes]
+        v = incoming / np.linalg.norm(incoming, axis=-1, keepdims=True)
         reflected = v - 2.0 * np.einsum("ij,ij->i", v, normal)[:, None] * normal
         shiny = reflected + roughness[material][:, None] * unit
         absorbed = metal & (np.einsum("ij,ij->i", shiny, normal) <= 0.0)  # `return {}`: the sample is black
         scatter = np.where(metal[:, None], shiny, lambert)
-        scatter /= np.linalg.norm(scatter, axis=-1, keepdims=True)
+        scatter /= np.maximum(np.linalg.norm(scatter, axis=-1, keepdims=True), 1e-300)
+        if refracts.any():
+            # dielectric_scatter, sm_ray_tracer.cpp:156-219, as written: the incoming direction is NOT normalised, nor is the new one
+            index_of_refraction = reflectivity[material]
+            d_n = np.einsum("ij,ij->i", incoming, normal)
+            from_inside = d_n > 0.0
+            outward_normal = np.where(from_inside[:, None], -normal, normal)
+            eta = np.where(from_inside, index_of_refraction, 1.0 / index_of_refraction)
+            length = np.linalg.norm(incoming, axis=-1)
+            cosine = np.where(from_inside, index_of_refraction * d_n / length, -d_n / length)
+            mirrored = incoming - 2.0 * d_n[:, None] * normal  # reflect(r.direction, hit.normal) (:188)
+            cos_i = -np.einsum("ij,ij->i", incoming, outward_normal)  # refract (:161-172)
+            sin2_t = eta * eta * (1.0 - cos_i * cos_i)
+            can_refract = ~(sin2_t > 1.0)
+            cos_t = np.sqrt(np.maximum(1.0 - sin2_t, 0.0))
+            refracted = eta[:, None] * incoming + (eta * cos_i - cos_t)[:, None] * outward_normal
+            r0 = ((1.0 - index_of_refraction) / (1.0 + index_of_refraction)) ** 2  # schlick (:174-179)
+            reflect_probability = np.where(can_refract, r0 + (1.0 - r0) * (1.0 - cosine) ** 5, 1.0)
+            u = np.zeros(lanes.size)
+            u[refracts] = streams.next(lanes[refracts])
+            through = np.where((u < reflect_probability)[:, None], mirrored, refracted)
+            scatter = np.where(refracts[:, None], through, scatter)
         throughput[lanes] = throughput[lanes] * attenuation_of[material]
         origin[lanes] = position
         direction[lanes] = scatter
@@ -162,24 +191,34 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("name,camera,width,height,spp,bounces", CASES)
-def test_the_oracle_agrees_with_an_independent_float64_restatement(name, camera, width, height, spp, bounces):
+@pytest.mark.parametrize("name,camera,width,height,spp,bounces,sm_materials", [c + (False,) for c in CASES] + [("dielectric", None, 96, 54, 16, 10, True), ("dielectric_plane", None, 80, 45, 12, 10, True)])
+def test_the_oracle_agrees_with_an_independent_float64_restatement(name, camera, width, height, spp, bounces, sm_materials):
+    """(the last two cases: sm_ray_tracer's scatter table, where dielectrics refract — the path of hip_sm_ray_tracer)"""
     scene = rt_amd.Scene.named(name).set_sampling(spp, bounces)
     if camera:
         scene.set_camera(*camera)
     pod = scene.describe(width, height)
     seed = 12345
-    _, oracle_mean, stats = oracle.render(pod, width, height, seed=seed)
-    mine = render_f64(pod, width, height, seed)
+    _, oracle_mean, stats = oracle.render(pod, width, height, seed=seed, sm_materials=sm_materials)
+    mine = render_f64(pod, width, height, seed, sm_materials)
     difference = np.abs(oracle_mean.astype(np.float64) - mine).max(axis=-1)
     # A sample that lands on the other side of a silhouette, of the min_hit_dist threshold or of the metal's absorption test
     # under float32 rounding changes a pixel's mean by up to (its weight)/spp — and everything downstream of it; such pixels
     # are rare.  Everywhere else the two agree to float32 rounding accumulated over a path.
     scale = max(1.0, float(mine.max()))
+    assert np.median(difference) <= 1e-6 * scale, (name, np.median(difference))  # (measured: 3e-8 .. 4e-8)
+    assert stats["primary_samples"] == width * height * spp
+    if sm_materials:
+        # A path that has been refracted INTO a sphere starts on its surface, and whether `e.e < r^2` calls that inside (far root:
+        # the ray leaves through the far side) or outside (near root ~ 0 < min_hit_dist: the ray passes through the sphere as if it
+        # were not there) is decided by the last bit of the hit position — in the reference as much as here.  float64 and float32
+        # toss that coin differently, so pixels that see a refracting sphere agree only on average: the rest of the frame must
+        # agree as closely as under mg semantics, the frame's mean colour to 1.5 % (measured: 0.4-0.5 %).
+        assert (difference <= 2e-4 * scale).mean() >= 0.90, (name, (difference <= 2e-4 * scale).mean())
+        assert np.allclose(oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)), rtol=1.5e-2), (oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)))
+        return
     assert (difference <= 2e-4 * scale).mean() >= 0.995, (name, (difference <= 2e-4 * scale).mean(), np.sort(difference.ravel())[-10:])
     assert (difference <= 1e-5 * scale).mean() >= 0.98, (name, (difference <= 1e-5 * scale).mean())
-    assert np.median(difference) <= 1e-6 * scale, (name, np.median(difference))  # (measured: 3e-8 .. 4e-8)
     # the frame as a whole: the mean colour, to 5e-5 relative (measured: 1e-6 .. 7e-6) — a systematic difference (a wrong factor,
     # a wrong draw order, a wrong tie rule, a wrong column layout) shows here at once
     assert np.allclose(oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)), rtol=5e-5), (oracle_mean.mean(axis=(0, 1)), mine.mean(axis=(0, 1)))
-    assert stats["primary_samples"] == width * height * spp
