@@ -212,9 +212,15 @@ namespace rt_hip
 			float fx, fy;		// pixel coordinates as floats
 			stream_keys keys;	// random streams of the pixel (contract.hpp): the key of its hash function and its counter stride
 			uint32_t counter;	// random stream position
-			uint32_t sample;	// index of the sample in flight
-			uint32_t sample_end; // one past the last sample of the chunk in flight
-			uint32_t bounces_left;
+			// The samples of an item, counted in STREAM POSITIONS: a sample's window starts at stride * (index << 12)
+			// (contract.hpp), so "the next sample" is one shift-and-add on the window start and nothing has to be multiplied
+			// per restart.  `window` = where the sample in flight started, `window_end` = where the first sample behind the
+			// item would start (the stride is odd and an index is below 2^20: distinct samples, distinct windows; index 0 is
+			// the one window that starts at position 0).
+			uint32_t window, window_end;
+			uint32_t sample;	 // [INDEXED kernels only] index of the sample in flight
+			uint32_t sample_end; // [INDEXED kernels only] one past the last sample of the item in flight
+			uint32_t bounces_left; // bounces the path may still make AFTER the segment in flight
 		};
 
 		// image row of row `local_row` of this rank's compact buffer (rt_hip_partition).  All branches are wave-uniform.
@@ -669,13 +675,26 @@ namespace rt_hip
 				}
 			};
 
+			// on to the next sample of the item in flight; false = that was the last one.  The lane's stream moves to the next
+			// sample's window (a restarting lane has no other use for its position).  The kernels that look at a sample's INDEX
+			// (half chunks park by it, rolling items publish by it) count indices; the others count windows only.
+			constexpr bool INDEXED = HALF || ROLLING;
+			const auto next_sample = [&]() -> bool
+			{
+				st.window += st.keys.stride << draws_per_sample_log2;
+				st.counter = st.window;
+				if (INDEXED)
+					return ++st.sample < st.sample_end;
+				return st.window != st.window_end;
+			};
+
 			// `colour += trace(...)` (:193) for the sample in flight, then the next sample of the chunk or the end of the item
 			const auto end_sample = [&](vec3 contribution)
 			{
 				if (HALF && ROLLING)
 				{
 					publish_sum(item_sums + 2u * (static_cast<size_t>(slot) * p.samples_per_pixel + st.sample), contribution);
-					if (++st.sample < st.sample_end)
+					if (next_sample())
 						RT_HIP_BECOME(lane_restart);
 					else
 					{
@@ -698,7 +717,7 @@ namespace rt_hip
 					}
 					else
 						st.chunk_sum = st.chunk_sum + contribution;
-					if (++st.sample < st.sample_end)
+					if (next_sample())
 						RT_HIP_BECOME(lane_restart);
 					else
 					{
@@ -713,7 +732,7 @@ namespace rt_hip
 					return;
 				}
 				st.chunk_sum = st.chunk_sum + contribution;
-				if (++st.sample < st.sample_end)
+				if (next_sample())
 					RT_HIP_BECOME(lane_restart);
 				else
 				{
@@ -805,7 +824,6 @@ namespace rt_hip
 				if (tracing)
 				{
 					RT_HIP_REGION(1); // query: probes
-					st.bounces_left--; // `if (!(max_bounces--)) return {}` (:157) is checked when the bounce is made, below
 					if (!SCALAR_SEGMENTS)
 						lane_segments++;
 					uint32_t kind;
@@ -931,8 +949,11 @@ namespace rt_hip
 					st.fy = static_cast<float>(gy);
 					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
-					st.sample = chunk * item_samples;
-					st.sample_end = min(st.sample + item_samples, p.samples_per_pixel);
+					const uint32_t first = chunk * item_samples, end = min(first + item_samples, p.samples_per_pixel);
+					st.sample = first;
+					st.sample_end = end;
+					st.window = st.counter = sample_counter(st.keys.stride, first);
+					st.window_end = sample_counter(st.keys.stride, end);
 					RT_HIP_BECOME(lane_restart);
 				};
 				// a free lane becomes the owner of item `item` of the tile at (x0, y0)
@@ -1028,17 +1049,18 @@ namespace rt_hip
 					break;
 
 				const bool restart = RT_HIP_IS(lane_restart);
-				if (__builtin_amdgcn_ballot_w64(shade || restart) != 0)
+				// (Every trip of a live wave has lanes here: no vote in front of the tail.  A restarting lane's stream already
+				// stands at its sample's window — next_sample / start_item put it there — so both kinds of lane draw from
+				// st.counter and nothing is selected or multiplied per trip.)
 				{
 					RT_HIP_REGION(8); // the fused tail: two draws
 					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
-					uint32_t counter = restart ? sample_counter(st.keys.stride, st.sample) : st.counter;
+					uint32_t counter = st.counter;
 					const uint32_t counter_at_start = counter;
 					// (as numerators k of u = k * 2^-24: the scaling folds into the jitter's fma and cancels in the unit vector)
 					float d0 = next_random_numerator(counter, st.keys);
 					float d1 = next_random_numerator(counter, st.keys);
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
-					bool absorbed = false;
 					bool unit_length = false; // `toward` is used as it is (sm's dielectric_scatter does not normalise)
 					if (shade && SM && scatter_kind == scatter_dielectric)
 					{
@@ -1070,11 +1092,15 @@ namespace rt_hip
 							const double x5 = (x2 * x2) * x;
 							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
 						}
-						counter = counter_at_start + st.keys.stride; // only d0 was consumed
+						st.counter = counter_at_start + st.keys.stride; // only d0 was consumed
 						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
 						unit_length = true;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
 						st.origin = hit_pos;
+						const bool dead = st.bounces_left == 0; // the next trace() call would return {} at :157-158
+						st.bounces_left--;
+						if (dead)
+							end_sample({ 0.0f, 0.0f, 0.0f });
 					}
 					else if (shade)
 					{
@@ -1090,6 +1116,7 @@ namespace rt_hip
 						const vec3 u = normalize_unit_cube_numerators({ d0, d1, d2 });
 						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
 						vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
+						bool absorbed = false;
 						if (metal)
 							absorbed = dot(scatter, normal) <= 0.0f; // (:135-136)
 						else if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon
@@ -1098,19 +1125,34 @@ namespace rt_hip
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z }; // attenuation * trace(...) (:171)
 						st.origin = hit_pos;
 						toward = scatter;
+						st.counter = counter;
+						// absorbed, or the next trace() call would return {} at :157-158 (`if (!(max_bounces--))`: the count is kept
+						// as the bounces still allowed after the segment in flight, and only a bounce touches it)
+						const bool dead = absorbed || st.bounces_left == 0;
+						st.bounces_left--;
+						if (dead)
+						{
+							RT_HIP_REGION(12); // absorbed or out of bounces: the sample is worth nothing
+							end_sample({ 0.0f, 0.0f, 0.0f });
+						}
 					}
 					else if (restart)
 					{
 						RT_HIP_REGION(10); // restart: primary ray
 						// worker lambda :189-193 — jittered position, un-project to near and far, build the primary ray
-						float jx = 0x1.0p23f, jy = 0x1.0p23f; // sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing
-						if (st.sample)
+						float jx = d0, jy = d1;
+						// sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing (:189).  Its window is the one
+						// that starts at stream position 0.  One restart in spp is such a sample, and a wave meets them all in its first
+						// trips: a vote keeps the two selects and the rewind out of every other trip.
+						if (__builtin_amdgcn_ballot_w64(counter_at_start == 0u) != 0)
 						{
-							jx = d0;
-							jy = d1;
+							asm volatile("; restart: some lane is at its pixel's sample 0" ::: "memory");
+							if (counter_at_start == 0u)
+							{
+								jx = jy = 0x1.0p23f;
+								counter = counter_at_start;
+							}
 						}
-						else
-							counter = counter_at_start;
 						const float px = fma(jx, random_scale, st.fx); // == fx + jx * 2^-24: the product is exact
 						const float py = fma(jy, random_scale, st.fy);
 						// rt's camera (w constant over the frame): near point and near-to-far vector are affine in (px, py) —
@@ -1146,13 +1188,13 @@ namespace rt_hip
 							toward = far_pos - near_pos; // vec3::direction(near, far) (:193)
 						}
 						st.throughput = { 1.0f, 1.0f, 1.0f };
-						st.bounces_left = p.max_bounces;
+						st.bounces_left = p.max_bounces - 1u;
+						st.counter = counter;
 						RT_HIP_BECOME(lane_trace);
 					}
 					if (shade || restart)
 					{
 						RT_HIP_REGION(11); // normalise the new direction
-						st.counter = counter;
 						if (SM)
 						{
 							const vec3 unit = normalize(unit_length ? vec3{ 0.0f, 0.0f, 1.0f } : toward);
@@ -1160,12 +1202,6 @@ namespace rt_hip
 						}
 						else
 							st.dir = normalize(toward);
-					}
-					// absorbed, or the next trace() call would return {} at :157-158: the sample is worth nothing
-					if (shade && (absorbed || st.bounces_left == 0))
-					{
-						RT_HIP_REGION(12); // absorbed or out of bounces
-						end_sample({ 0.0f, 0.0f, 0.0f });
 					}
 				}
 			}
