@@ -68,8 +68,8 @@ def lib() -> C.CDLL:
         l.oracle_pack.argtypes = [C.c_float] * 3
         l.oracle_sky.restype = None
         l.oracle_sky.argtypes = [C.c_float, C.c_void_p]
-        l.oracle_primary_ray.restype = None
-        l.oracle_primary_ray.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        l.oracle_primary_ray.restype = C.c_int
+        l.oracle_primary_ray.argtypes = [C.POINTER(RtHipScene), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
         l.oracle_hits_box.restype = C.c_int
         l.oracle_hits_box.argtypes = [C.c_void_p] * 5
         l.oracle_dielectric_direction.restype = None
@@ -127,6 +127,8 @@ def render_mt19937(scene: RtHipScene, width: int, height: int, fixed_seed: int =
 
 
 def random(seed: int, pixel: int, sample: int, n: int) -> np.ndarray:
+    """The first n numbers of the stream of (pixel, sample), flattened: the three draws of its first generator step, then
+    of its second, ... (contract v4: one step per random<T>() call)."""
     out = np.empty(n, dtype=np.float32)
     lib().oracle_random(seed, pixel, sample, n, out.ctypes.data)
     return out
@@ -200,11 +202,13 @@ def sky(dir_y: float) -> np.ndarray:
     return out
 
 
-def primary_ray(scene: RtHipScene, width: int, height: int, px: float, py: float):
+def primary_ray(scene: RtHipScene, width: int, height: int, x: int, y: int, ka: float = 2.0**23, kb: float = 2.0**23, want_form: bool = False):
+    """(origin, direction) of the primary ray of pixel (x, y) whose jitter is (ka, kb) * 2^-24 — the numerators of one
+    generator step; the default is the pixel centre.  want_form: also whether the matrix was taken as a pinhole camera's."""
     o = np.empty(3, dtype=np.float32)
     d = np.empty(3, dtype=np.float32)
-    lib().oracle_primary_ray(C.byref(scene), width, height, px, py, o.ctypes.data, d.ctypes.data)
-    return o, d
+    pinhole = lib().oracle_primary_ray(C.byref(scene), width, height, x, y, ka, kb, o.ctypes.data, d.ctypes.data)
+    return (o, d, bool(pinhole)) if want_form else (o, d)
 
 
 def dielectric_direction(direction, normal, reflectivity: float, u: float):

@@ -14,10 +14,12 @@
 //   pixel addressing ............ src/image.hpp:143-159
 //
 // The vector/ray arithmetic itself lives in marzer/muu (absent offline).  The formulas chosen for it are
-// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v3": v1's floating-point rules + per-pixel keyed
-// random streams (v2) + normalize()'s reciprocal square root in one step (v3)) is this project's own and is what
-// the GPU kernels reproduce bit for bit.  The reference is built with -ffast-math -ffp-contract=fast
-// (meson.build:153-160), so it defines no operation order of its own.
+// SURVEY.md §8c's; the OPERATION ORDER below ("arithmetic contract v4": v1's floating-point rules + per-pixel keyed
+// random streams (v2) + normalize()'s reciprocal square root in one step (v3) + one generator step per random<vecN>()
+// and primary rays from a per-pixel base (v4)) is this project's own and is what the GPU kernels reproduce bit for
+// bit.  The reference is built with -ffast-math -ffp-contract=fast (meson.build:153-160), so it defines no operation
+// order of its own, and its generator (std::mt19937 seeded from std::random_device, src/random.cpp:9-26) pins nothing
+// about the random numbers but that they are uniform and independent.
 //
 // Arithmetic contract — every value is IEEE-754 binary32, round-to-nearest-even, subnormals kept;
 // no contraction or reassociation except the fmaf() written out here; sqrtf and '/' are correctly rounded:
@@ -28,9 +30,17 @@
 //   lerp(a,b,t)       = fmaf(b - a, t, a) per component
 //   transform_position(M,v): row_r = fmaf(M[r][0],v.x, fmaf(M[r][1],v.y, fmaf(M[r][2],v.z, M[r][3])));
 //                            xyz = row_0..2 * (1.0f / row_3)       (the preview, and primary rays of a matrix with varying w)
-//   primary ray (v3)       : for a matrix whose w is constant over the frame (rt's camera) the near point and the
-//                            near-to-far vector are affine in the pixel position: constants in binary64 (make_frame),
-//                            origin_c = fmaf(o1_c,px, fmaf(o2_c,py, o0_c)), toward_c likewise; dir = normalize(toward)
+//   primary ray (v4)       : PINHOLE camera (rt's: w constant over the frame and all near-to-far lines through one
+//                            eye point; constants in binary64, make_frame): the near-to-far vector is affine in the
+//                            pixel position — evaluated once per PIXEL at its corner, base_c = fmaf(d1_c, x,
+//                            fmaf(d2_c, y, d0_c)), and moved per SAMPLE by the jitter's numerators (ka, kb; u = k * 2^-24):
+//                            toward_c = fmaf(j1_c, ka, fmaf(j2_c, kb, base_c)), j = d * 2^-24; dir = normalize(toward);
+//                            origin_c = fmaf(kappa, toward_c, eye_c) — the near point, which lies on the line from the
+//                            eye at the fixed fraction kappa = near / (far - near) of the near-to-far vector.
+//                            ANY OTHER matrix: homogeneous near / far points N, F (four fmaf rows each, as
+//                            transform_position); origin = N.xyz * (1.0f / N.w); toward_c = fmaf(F_c, N.w, -(N_c * F.w)),
+//                            negated if N.w * F.w < 0 — far/F.w - near/N.w times the positive factor |N.w F.w|, which
+//                            normalize() removes: one division per sample instead of two.
 //   pixel sum               : samples are added in CHUNKS of 16 consecutive samples (each chunk summed in sample
 //                            order, starting from 0), and the chunk sums are added in chunk order (left fold starting
 //                            from the first chunk's sum).  For spp <= 16 this is the reference's plain sequential
@@ -124,13 +134,24 @@ namespace
 	//   (fa, fb) = low and high half of mix64(seed), mix64 = the splitmix64 finaliser (a bijection of 64-bit words)
 	//   k        = hash32(pixel_index ^ fa)          function key — a bijection of the pixel index: never shared in a frame
 	//   stride   = hash32(k ^ fb) | 1                counter stride (odd)
-	//   counter  = stride * (sample_index * 4096)    before the first draw of a sample (mod 2^32; 4096 draws reserved per sample)
-	//   draw     : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
-	//              x *= 0x846ca68b;  u = float(x >> 8) * 2^-24      in [0, 1)
-	//              (the top 24 bits of the last product as they are; lowbias32's closing xorshift would only touch the
+	//   counter  = stride * (sample_index * 4096)    before the first step of a sample (mod 2^32; 4096 steps reserved per sample)
+	//   step     : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
+	//              a = x * 0x846ca68b;  b = x * MB;  c = x * MC     (mod 2^32)
+	//              u_a = float(a >> 8) * 2^-24, u_b, u_c likewise   in [0, 1)
+	//              (the top 24 bits of the products as they are; lowbias32's closing xorshift would only touch a
 	//              draw's lowest 8 bits)
+	// Contract v4: ONE step serves one call of random<T>() — random<float>() takes u_a, random<vec2>() (u_a, u_b),
+	// random<vec3>() (u_a, u_b, u_c), in the reference's brace-init order (src/random.hpp:37-46).  Under v2/v3 every
+	// component was a step of its own: three hashes per unit vector, two per jitter — a fifth of the small kernel's
+	// vector instructions (profiles/r04/headline_basic_1080p_256spp/pmc_summary.csv).  The three words of a step are
+	// the multiples x * M2 * (1, A, A^2) of the mixed word x, with M2 = lowbias32's second multiplier and
+	// A = 0xadb4a92d (Steele & Vigna, "Computationally easy, spectrally good multipliers", the 32-bit LCG multiplier):
+	// MB = M2 * A, MC = M2 * A^2 (mod 2^32).  Seen together they are a point of the rank-1 lattice generated by
+	// (1, A, A^2) / 2^32 — what three consecutive outputs of that congruential generator are — picked by a hashed index;
+	// its figures of merit are 0.976 in two and 0.936 in three dimensions (tools/rng_lattice.py), i.e. 2^32 possible
+	// unit-cube points about 1/1700 apart in every direction.  u_a alone is exactly the v2/v3 draw.
 	// Two pixels with different strides evaluate their (different) functions at a common counter only at isolated
-	// draws, never along a run.  (Contract v1 drew every pixel from ONE shared hash32 sequence at a hashed offset; a
+	// steps, never along a run.  (Contract v1 drew every pixel from ONE shared hash32 sequence at a hashed offset; a
 	// 1920x1080x256 frame draws 3.6e9 numbers, so most sample windows overlapped another pixel's and some were identical.)
 	inline uint32_t hash32(uint32_t x)
 	{
@@ -168,28 +189,40 @@ namespace
 			  counter{ stride * (sample_index << 12) }
 		{}
 
-		// random<float>(), src/random.hpp:12-17 / src/random.cpp:20-26: uniform in [0, 1)
-		float next()
+		// one generator step: the numerators k (0 <= k < 2^24) of the three draws u = k * 2^-24
+		struct step
+		{
+			uint32_t a, b, c;
+		};
+		static constexpr uint32_t mul_a = 0x846ca68bu;					   // lowbias32's second multiplier
+		static constexpr uint32_t lattice = 0xadb4a92du;				   // A
+		static constexpr uint32_t mul_b = mul_a * lattice;				   // (mod 2^32)
+		static constexpr uint32_t mul_c = mul_a * lattice * lattice;	   // (mod 2^32)
+		step next_step()
 		{
 			counter += stride;
 			uint32_t x = counter;
 			x ^= x >> 16;
 			x = x * 0x7feb352du + function_key;
 			x ^= x >> 15;
-			x *= 0x846ca68bu;
-			return static_cast<float>(x >> 8) * 0x1.0p-24f;
+			return { (x * mul_a) >> 8, (x * mul_b) >> 8, (x * mul_c) >> 8 };
 		}
+
+		// random<float>(), src/random.hpp:12-17 / src/random.cpp:20-26: uniform in [0, 1)
+		float next() { return static_cast<float>(next_step().a) * 0x1.0p-24f; }
 	};
 
-	// random_unit_vector(), src/random.hpp:57-66: components drawn x, y, z (brace-init order, :43-46), redrawn
-	// only if exactly zero, then normalised.  All components are >= 0: the direction lies in the positive octant.
+	// random_unit_vector(), src/random.hpp:57-66: components x, y, z of random<vec3>() (brace-init order, :43-46: one
+	// step under contract v4), redrawn only if exactly zero, then normalised.  All components are >= 0: the direction
+	// lies in the positive octant.
 	inline vec3 random_unit_vector(random_stream& rng)
 	{
 		while (true)
 		{
-			const float x = rng.next();
-			const float y = rng.next();
-			const float z = rng.next();
+			const random_stream::step k = rng.next_step();
+			const float x = static_cast<float>(k.a) * 0x1.0p-24f;
+			const float y = static_cast<float>(k.b) * 0x1.0p-24f;
+			const float z = static_cast<float>(k.c) * 0x1.0p-24f;
 			if (x == 0.0f && y == 0.0f && z == 0.0f)
 				continue;
 			return normalize({ x, y, z });
@@ -211,10 +244,13 @@ namespace
 		std::vector<material> materials;
 		uint32_t width, height;
 		float sx, sy; // 2 / W, 2 / H
-		// contract v3: primary rays of a camera whose w is constant over the frame (rt's: camera.hpp:122-137) — near point
-		// and near-to-far vector as affine functions of the pixel position, constants worked out in binary64
-		bool affine_rays;
-		float ray_o0[3], ray_o1[3], ray_o2[3], ray_d0[3], ray_d1[3], ray_d2[3];
+		// contract v4: primary rays of a pinhole camera (rt's: camera.hpp:122-137) — the near-to-far vector as an affine
+		// function of the pixel position (d0 + d1 x + d2 y), the jitter's share of it per numerator (j = d * 2^-24), and
+		// the near point as eye + kappa * (near-to-far); constants worked out in binary64
+		bool pinhole_rays;
+		float ray_d0[3], ray_d1[3], ray_d2[3], ray_j1[3], ray_j2[3], ray_eye[3], ray_kappa;
+		// any other matrix: rows of the homogeneous near / far points
+		float mx[4], my[4], k_near[4], k_far[4];
 		frame_keys keys;
 		int trace_order;
 		bool sm_materials;
@@ -232,27 +268,55 @@ namespace
 			// viewport::screen_to_world (camera.hpp:42-48) un-projects ndc = (2x/W - 1, -2y/H + 1, depth) through the inverse
 			// view-projection M and divides by w.  For rt's camera the last row of M has no x and no y term, so w depends on
 			// the depth alone: near(px, py) = (M0 X + M1 Y + k_near) / w_near is affine in the pixel position, and so is
-			// far - near.  The constants are worked out here in binary64, in this order of operations, and rounded to
-			// binary32 once (rt_amd/csrc/api.hip has the same lines); a ray then costs two fmas per component.
+			// far - near.  Its frustum is a pinhole's: every near-to-far line passes through the eye, so that
+			// near = eye + kappa * (far - near) with ONE kappa = n / (f - n) for the whole frame.  The constants are worked out
+			// here in binary64, in this order of operations, and rounded to binary32 once (rt_amd/csrc/render.hip has the same
+			// lines).  Whether a matrix IS a pinhole's is decided from the same numbers: w constant over the frame, and the
+			// near point's motion per pixel within 1e-5 (relative) of kappa times the near-to-far vector's — a slack of
+			// 1e-10 of a pixel step, far below what binary32 resolves; an orthographic or sheared frustum fails it and takes the
+			// general form, like a matrix whose w varies.
 			const float* M = s->inverse_view_projection;
-			float k_near[4], k_far[4];
 			for (int r = 0; r < 4; r++)
 			{
-				k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
-				k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
+				f.mx[r] = M[r * 4 + 0];
+				f.my[r] = M[r * 4 + 1];
+				f.k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
+				f.k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
 			}
-			f.affine_rays = M[12] == 0.0f && M[13] == 0.0f && k_near[3] != 0.0f && k_far[3] != 0.0f && std::isfinite(k_near[3]) && std::isfinite(k_far[3]);
-			if (f.affine_rays)
+			const float* k_near = f.k_near;
+			const float* k_far = f.k_far;
+			f.pinhole_rays = false;
+			if (M[12] == 0.0f && M[13] == 0.0f && k_near[3] != 0.0f && k_far[3] != 0.0f && std::isfinite(k_near[3]) && std::isfinite(k_far[3]))
 			{
 				const double sx = 2.0 / static_cast<double>(w), sy = -(2.0 / static_cast<double>(h));
 				const double iwn = 1.0 / static_cast<double>(k_near[3]), iwf = 1.0 / static_cast<double>(k_far[3]);
+				double o0[3], o1[3], o2[3], d0[3], d1[3], d2[3];
 				for (int c = 0; c < 3; c++)
 				{
 					const double mx = M[c * 4 + 0], my = M[c * 4 + 1], kn = k_near[c], kf = k_far[c];
-					const double o1 = mx * sx * iwn, o2 = my * sy * iwn, o0 = (kn - mx + my) * iwn;
+					o1[c] = mx * sx * iwn, o2[c] = my * sy * iwn, o0[c] = (kn - mx + my) * iwn;
 					const double e1 = mx * sx * iwf, e2 = my * sy * iwf, e0 = (kf - mx + my) * iwf;
-					f.ray_o0[c] = static_cast<float>(o0), f.ray_o1[c] = static_cast<float>(o1), f.ray_o2[c] = static_cast<float>(o2);
-					f.ray_d0[c] = static_cast<float>(e0 - o0), f.ray_d1[c] = static_cast<float>(e1 - o1), f.ray_d2[c] = static_cast<float>(e2 - o2);
+					d0[c] = e0 - o0[c], d1[c] = e1 - o1[c], d2[c] = e2 - o2[c];
+				}
+				const double dd = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2] + d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+				const double od = o1[0] * d1[0] + o1[1] * d1[1] + o1[2] * d1[2] + o2[0] * d2[0] + o2[1] * d2[1] + o2[2] * d2[2];
+				const double kappa = od / dd;
+				double worst = 0.0, scale = 0.0;
+				for (int c = 0; c < 3; c++)
+				{
+					worst = std::fmax(worst, std::fmax(std::fabs(o1[c] - kappa * d1[c]), std::fabs(o2[c] - kappa * d2[c])));
+					scale = std::fmax(scale, std::fmax(std::fabs(o1[c]), std::fabs(o2[c])));
+				}
+				if (dd > 0.0 && std::isfinite(kappa) && worst <= 1.0e-5 * scale) // (a NaN anywhere fails the comparison)
+				{
+					f.pinhole_rays = true;
+					f.ray_kappa = static_cast<float>(kappa);
+					for (int c = 0; c < 3; c++)
+					{
+						f.ray_d0[c] = static_cast<float>(d0[c]), f.ray_d1[c] = static_cast<float>(d1[c]), f.ray_d2[c] = static_cast<float>(d2[c]);
+						f.ray_j1[c] = f.ray_d1[c] * 0x1.0p-24f, f.ray_j2[c] = f.ray_d2[c] * 0x1.0p-24f;
+						f.ray_eye[c] = static_cast<float>(o0[c] - kappa * d0[c]);
+					}
 				}
 			}
 		}
@@ -290,19 +354,40 @@ namespace
 		return transform_position(f.scene->inverse_view_projection, ndc);
 	}
 
-	inline ray primary_ray(const frame& f, float px, float py)
+	// The primary ray of pixel (x, y) whose jitter is (ka, kb) * 2^-24 (numerators of one generator step; 2^23 each for the
+	// centre): mg_ray_tracer.cpp:189-193.
+	inline ray primary_ray(const frame& f, uint32_t x, uint32_t y, float ka, float kb)
 	{
-		if (f.affine_rays) // near point and near-to-far vector straight from the pixel position (see make_frame)
+		const float fx = static_cast<float>(x), fy = static_cast<float>(y);
+		if (f.pinhole_rays) // near-to-far vector from the pixel's base and the jitter, near point from it (see make_frame)
 		{
-			const vec3 near_pos = { std::fmaf(f.ray_o1[0], px, std::fmaf(f.ray_o2[0], py, f.ray_o0[0])), std::fmaf(f.ray_o1[1], px, std::fmaf(f.ray_o2[1], py, f.ray_o0[1])),
-									std::fmaf(f.ray_o1[2], px, std::fmaf(f.ray_o2[2], py, f.ray_o0[2])) };
-			const vec3 toward = { std::fmaf(f.ray_d1[0], px, std::fmaf(f.ray_d2[0], py, f.ray_d0[0])), std::fmaf(f.ray_d1[1], px, std::fmaf(f.ray_d2[1], py, f.ray_d0[1])),
-								  std::fmaf(f.ray_d1[2], px, std::fmaf(f.ray_d2[2], py, f.ray_d0[2])) };
-			return { near_pos, normalize(toward) }; // mg_ray_tracer.cpp:190-193
+			vec3 toward, origin;
+			float* const t = &toward.x;
+			float* const o = &origin.x;
+			for (int c = 0; c < 3; c++)
+			{
+				const float base = std::fmaf(f.ray_d1[c], fx, std::fmaf(f.ray_d2[c], fy, f.ray_d0[c])); // once per pixel
+				t[c] = std::fmaf(f.ray_j1[c], ka, std::fmaf(f.ray_j2[c], kb, base));
+				o[c] = std::fmaf(f.ray_kappa, t[c], f.ray_eye[c]);
+			}
+			return { origin, normalize(toward) }; // :190-193
 		}
-		const vec3 near_pos = screen_to_world(f, px, py, 0.0f); // mg_ray_tracer.cpp:190
-		const vec3 far_pos = screen_to_world(f, px, py, 1.0f);	// :191
-		return { near_pos, direction(near_pos, far_pos) };		// :193
+		// any other matrix: screen_to_world (camera.hpp:42-48) for depth 0 and 1 in homogeneous form; ONE division
+		const float px = std::fmaf(ka, 0x1.0p-24f, fx), py = std::fmaf(kb, 0x1.0p-24f, fy); // == fx + ka * 2^-24: the product is exact
+		const float ndc_x = std::fmaf(px, f.sx, -1.0f), ndc_y = std::fmaf(py, -f.sy, 1.0f);
+		float N[4], F[4];
+		for (int r = 0; r < 4; r++)
+		{
+			N[r] = std::fmaf(f.mx[r], ndc_x, std::fmaf(f.my[r], ndc_y, f.k_near[r]));
+			F[r] = std::fmaf(f.mx[r], ndc_x, std::fmaf(f.my[r], ndc_y, f.k_far[r]));
+		}
+		const float inv_wn = 1.0f / N[3];
+		const vec3 near_pos = { N[0] * inv_wn, N[1] * inv_wn, N[2] * inv_wn }; // :190
+		// far / F.w - near / N.w (:191,193) = (F N.w - N F.w) / (N.w F.w): the numerator, with the denominator's sign
+		vec3 toward = { std::fmaf(F[0], N[3], -(N[0] * F[3])), std::fmaf(F[1], N[3], -(N[1] * F[3])), std::fmaf(F[2], N[3], -(N[2] * F[3])) };
+		if (N[3] * F[3] < 0.0f)
+			toward = { -toward.x, -toward.y, -toward.z };
+		return { near_pos, normalize(toward) };
 	}
 
 	// ---- intersection (muu::ray::hits; formulas per SURVEY.md §8c) ------------------------------------------------
@@ -616,15 +701,14 @@ namespace
 		for (uint32_t i = 0, e = s.samples_per_pixel; i < e; i++)
 		{
 			random_stream rng{ f.keys, pixel_index, i };
-			float jx = 0.5f, jy = 0.5f; // sample 0 goes through the pixel centre (:189)
+			float ka = 0x1.0p23f, kb = 0x1.0p23f; // sample 0 goes through the pixel centre and draws nothing (:189)
 			if (i)
 			{
-				jx = rng.next();
-				jy = rng.next();
+				const random_stream::step k = rng.next_step(); // random<vec2>(): one step
+				ka = static_cast<float>(k.a);
+				kb = static_cast<float>(k.b);
 			}
-			const float px = static_cast<float>(x) + jx;
-			const float py = static_cast<float>(y) + jy;
-			const ray r = primary_ray(f, px, py);
+			const ray r = primary_ray(f, x, y, ka, kb);
 			const vec3 sample = f.trace_order == ORACLE_TRACE_RECURSIVE ? trace_recursive(f, r, s.max_bounces, rng, c)
 																		 : trace_iterative(f, r, s.max_bounces, rng, c);
 			chunk = chunk + sample;
@@ -787,9 +871,15 @@ extern "C" int oracle_render(const rt_hip_scene* scene,
 
 extern "C" void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out)
 {
+	// the stream of (pixel, sample) flattened: u_a, u_b, u_c of its first step, then of its second, ...
 	random_stream rng{ make_frame_keys(seed), pixel, sample };
-	for (uint32_t i = 0; i < n; i++)
-		out[i] = rng.next();
+	for (uint32_t i = 0; i < n; i += 3)
+	{
+		const random_stream::step k = rng.next_step();
+		const uint32_t word[3] = { k.a, k.b, k.c };
+		for (uint32_t j = 0; j < 3 && i + j < n; j++)
+			out[i + j] = static_cast<float>(word[j]) * 0x1.0p-24f;
+	}
 }
 
 extern "C" void oracle_stream_keys(uint64_t seed, uint32_t n, const uint32_t* pixels, const uint32_t* samples, uint32_t* out_function_key, uint32_t* out_stride, uint32_t* out_counter)
@@ -861,16 +951,17 @@ extern "C" void oracle_sky(float dir_y, float* out_rgb)
 	out_rgb[2] = c.z;
 }
 
-extern "C" void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir)
+extern "C" int oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, uint32_t x, uint32_t y, float ka, float kb, float* out_origin, float* out_dir)
 {
 	const frame f = make_frame(scene, width, height, 0, ORACLE_TRACE_ITERATIVE);
-	const ray r = primary_ray(f, px, py);
+	const ray r = primary_ray(f, x, y, ka, kb);
 	out_origin[0] = r.origin.x;
 	out_origin[1] = r.origin.y;
 	out_origin[2] = r.origin.z;
 	out_dir[0] = r.dir.x;
 	out_dir[1] = r.dir.y;
 	out_dir[2] = r.dir.z;
+	return f.pinhole_rays ? 1 : 0;
 }
 
 extern "C" void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob)

@@ -68,6 +68,7 @@ int oracle_render_mt19937(const rt_hip_scene* scene,
 						  oracle_stats* stats /* nullable */);
 
 /* Leaf functions, for known-answer tests and device KATs. */
+/* the first n numbers of the random stream of (pixel, sample): the three draws of its first generator step, of its second, ... */
 void oracle_random(uint64_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out);
 /* state of the random stream of (pixel, sample) before its first draw: the pixel's function key and stride, and the counter */
 void oracle_stream_keys(uint64_t seed, uint32_t n, const uint32_t* pixels, const uint32_t* samples, uint32_t* out_function_key, uint32_t* out_stride, uint32_t* out_counter);
@@ -88,7 +89,9 @@ void oracle_sky(float dir_y, float* out_rgb);				   /* mg_ray_tracer.cpp:164 */
 void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob);
 /* ray vs axis-aligned box (center, half extents): 1 = hit and *out_t set.  The slab test of the preview. */
 int oracle_hits_box(const float* origin, const float* dir, const float* center, const float* extents, float* out_t);
-void oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, float px, float py, float* out_origin, float* out_dir);
+/* primary ray of pixel (x, y) for the jitter (ka, kb) * 2^-24 (numerators of one generator step; 2^23 = the centre);
+ * returns 1 if the matrix was taken as a pinhole camera's, 0 if it went through the general (one-division) form */
+int oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, uint32_t x, uint32_t y, float ka, float kb, float* out_origin, float* out_dir);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
-// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v3"
+// rt_amd/csrc/contract.hpp — device-side leaf functions of the path, written to "arithmetic contract v4"
 // (v2 = v1's floating-point rules with per-pixel keyed random streams; v3 = v2 with normalize()'s reciprocal square
-// root taken in one step instead of as a rounded square root followed by a rounded reciprocal).
+// root taken in one step instead of as a rounded square root followed by a rounded reciprocal; v4 = v3 with one
+// generator step per random<T>() call and primary rays built from a per-pixel base: kernels.hpp, frame_params).
 //
 // Every function here is the gfx950 counterpart of a reference function on the mg_ray_tracer path and produces
 // bit-identical binary32 results to the CPU oracle:
@@ -204,9 +205,9 @@ namespace rt_hip
 	//   k         = hash32(pixel ^ fa)            the pixel's FUNCTION key: a bijection of the pixel index, so no two
 	//                                             pixels of a frame ever draw through the same function
 	//   stride    = hash32(k ^ fb) | 1            the pixel's counter stride (odd: m -> stride * m is a bijection)
-	//   counter   = stride * (sample * 4096)      before the first draw of a sample: 4096 draws reserved per sample
-	//   draw      : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
-	//               x *= 0x846ca68b;  u = (x >> 8) * 2^-24
+	//   counter   = stride * (sample * 4096)      before the first step of a sample: 4096 steps reserved per sample
+	//   draw (v2) : counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;
+	//               x *= 0x846ca68b;  u = (x >> 8) * 2^-24               (v4: three draws per such step, see below)
 	// i.e. the lowbias32 finaliser with the pixel's key added between its two rounds, walked with the pixel's stride,
 	// and the top 24 bits of the last product taken as they are (lowbias32's closing x ^= x >> 16 only touches the low
 	// half of the word: it would change the draw's lowest 8 bits and cost two instructions).  For a fixed key the map
@@ -254,31 +255,45 @@ namespace rt_hip
 		return x;
 	}
 
-	// random<float>(), src/random.hpp:12-17: uniform in [0, 1), as the integer k of u = k * 2^-24 (0 <= k < 2^24, exact)
+	// Contract v4: ONE generator step serves one call of random<T>() (src/random.hpp:12-46) and yields up to three draws:
+	//   counter += stride;  x = counter;  x ^= x >> 16;  x = x * 0x7feb352d + k;  x ^= x >> 15;          the step's WORD
+	//   a = x * M2,  b = x * M2 A,  c = x * M2 A^2  (mod 2^32);   u = (product >> 8) * 2^-24               its draws
+	// with M2 = lowbias32's second multiplier and A = 0xadb4a92d: random<float>() takes u_a, random<vec2>() (u_a, u_b),
+	// random<vec3>() (u_a, u_b, u_c).  The three products are a point of the rank-1 lattice (1, A, A^2) / 2^32 picked by a
+	// hashed index (oracle/cpu_ref.cpp, "random streams", has the figures).  Per draw that is a multiply, a shift and a
+	// conversion on top of a third (vec3) or a half (vec2) of a hash, where v2/v3 spent a whole hash on every component.
+	constexpr uint32_t step_mul_a = 0x846ca68bu;
+	constexpr uint32_t step_lattice = 0xadb4a92du;
+	constexpr uint32_t step_mul_b = step_mul_a * step_lattice;				  // (mod 2^32)
+	constexpr uint32_t step_mul_c = step_mul_a * step_lattice * step_lattice; // (mod 2^32)
 	constexpr float random_scale = 0x1.0p-24f;
 	struct stream_keys
 	{
 		uint32_t function_key, stride;
 	};
-	__device__ __forceinline__ float next_random_numerator(uint32_t& counter, stream_keys keys)
+	__device__ __forceinline__ uint32_t next_step_word(uint32_t& counter, stream_keys keys)
 	{
 		counter += keys.stride;
-		return static_cast<float>(keyed_hash32(counter, keys.function_key) >> 8);
+		uint32_t x = counter;
+		x ^= x >> 16;
+		x = x * 0x7feb352du + keys.function_key;
+		x ^= x >> 15;
+		return x;
 	}
-	__device__ __forceinline__ float next_random(uint32_t& counter, stream_keys keys) { return next_random_numerator(counter, keys) * random_scale; }
+	// a draw of the step as the integer k of u = k * 2^-24 (0 <= k < 2^24, exact as a float)
+	__device__ __forceinline__ float step_numerator(uint32_t product) { return static_cast<float>(product >> 8); }
 
 	// random_unit_vector(), src/random.hpp:57-66 (positive octant only)
 	__device__ __forceinline__ vec3 random_unit_vector(uint32_t& counter, stream_keys keys)
 	{
-		float x, y, z;
+		uint32_t a, b, c;
 		do
 		{
-			x = next_random(counter, keys);
-			y = next_random(counter, keys);
-			z = next_random(counter, keys);
+			const uint32_t word = next_step_word(counter, keys);
+			a = word * step_mul_a, b = word * step_mul_b, c = word * step_mul_c;
 		}
-		while (x == 0.0f && y == 0.0f && z == 0.0f);
-		return normalize_unit_cube_draw({ x, y, z });
+		while (((a | b | c) >> 8) == 0u); // x == 0 && y == 0 && z == 0
+		return normalize_unit_cube_numerators({ step_numerator(a), step_numerator(b), step_numerator(c) });
 	}
 
 	// ---- intersection (muu::ray::hits) --------------------------------------------------------

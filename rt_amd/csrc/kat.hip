@@ -71,9 +71,15 @@ namespace
 		stream_keys keys;
 		keys.function_key = pixel_function_key(frame.a, pixel);
 		keys.stride = pixel_stride(frame.b, keys.function_key);
+		// the stream flattened, as oracle_random has it: the three draws of the first step, of the second, ...
 		uint32_t counter = sample_counter(keys.stride, sample);
-		for (uint32_t i = 0; i < n; i++)
-			out[i] = next_random(counter, keys);
+		for (uint32_t i = 0; i < n; i += 3u)
+		{
+			const uint32_t word = next_step_word(counter, keys);
+			const uint32_t product[3] = { word * step_mul_a, word * step_mul_b, word * step_mul_c };
+			for (uint32_t j = 0; j < 3u && i + j < n; j++)
+				out[i + j] = step_numerator(product[j]) * random_scale;
+		}
 	}
 
 	__global__ __launch_bounds__(block_threads) void kat_closest_hit(const device_scene s,

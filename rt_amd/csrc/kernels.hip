@@ -209,7 +209,7 @@ namespace rt_hip
 			vec3 origin, dir;	// current ray
 			vec3 throughput;	// product of attenuations so far (trace unrolled front to back)
 			vec3 chunk_sum;		// running sum of the chunk of samples in flight (:186,193)
-			float fx, fy;		// pixel coordinates as floats
+			vec3 base;			// pinhole camera: the near-to-far vector through the pixel's corner (frame_params); any other: (x, y, -) of the pixel
 			stream_keys keys;	// random streams of the pixel (contract.hpp): the key of its hash function and its counter stride
 			uint32_t counter;	// random stream position
 			// The samples of an item, counted in STREAM POSITIONS: a sample's window starts at stride * (index << 12)
@@ -448,11 +448,10 @@ namespace rt_hip
 																	  uint32_t* pixel_done)			 // [NS < 0] items arrived per pixel (zeroed in front of every launch)
 		{
 			extern __shared__ float4 lds[];
-			// [NS > 0] 8 geometry + 8 shading float4s, 8 metal flags | [NS == 0] all primitives; then the chunk slots
+			// [NS > 0] 8 geometry (with the scatter function) + 8 shading float4s | [NS == 0] all primitives; then the chunk slots
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
-			uint32_t* const lds_scatter = reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres);
-			const uint32_t table_float4s = NS > 0 ? (2 * scalar_max_spheres + scalar_max_spheres / 4) : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
+			const uint32_t table_float4s = NS > 0 ? 2 * scalar_max_spheres : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -460,9 +459,10 @@ namespace rt_hip
 #pragma unroll
 					for (int i = 0; i < NS + NP; i++) // constant indices: the argument block is never indexed dynamically
 					{
-						lds_geometry[i] = small.geometry[i];
+						// (what a hit looks up: the centre / the normal, and in the fourth word — the scan has radius^2 / d from the
+						// scalar registers — the scatter function: ONE 16-byte read for both)
+						lds_geometry[i] = make_float4(small.geometry[i].x, small.geometry[i].y, small.geometry[i].z, __uint_as_float(small.scatter[i]));
 						lds_shading[i] = small.shading[i];
-						lds_scatter[i] = small.scatter[i];
 					}
 				}
 			}
@@ -477,6 +477,7 @@ namespace rt_hip
 			uint32_t region_runs[device_counters::regions] = {}, region_lanes[device_counters::regions] = {};
 #endif
 			constexpr bool ROLLING = NS < 0;
+			constexpr bool PINHOLE_ONLY = NS > 0 && !GC, GENERAL_ONLY = NS > 0 && GC; // the camera form a scalar-register kernel is built for
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
 			const uint32_t chunk_items = q.chunks << q.pixels_log2;	   // chunks of one pixel tile: P x K
@@ -817,9 +818,8 @@ namespace rt_hip
 				}
 
 				bool shade = false;
-				vec3 normal, base, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
+				vec3 normal, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
 				float4 shading;
-				float spread = 1.0f;
 				uint32_t scatter_kind = scatter_lambert;
 				if (tracing)
 				{
@@ -914,20 +914,10 @@ namespace rt_hip
 							RT_HIP_REGION(3); // hit: lookups + normal
 							const float4 g = lds_geometry[small_index];
 							shading = lds_shading[small_index];
-							scatter_kind = lds_scatter[small_index];
+							scatter_kind = __float_as_uint(g.w);
 							normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
 							if (NP > 0 && kind == 2u)
 								normal = { g.x, g.y, g.z }; // the plane's normal as it is, not flipped toward the ray (:58)
-						}
-						base = normal;
-						if (scatter_kind == scatter_metal)
-						{
-							RT_HIP_REGION(5); // metal: normalise the incoming direction, reflect
-							// reflect(normalize(r.direction), n) (:133, common.hpp:100-103)
-							const vec3 v = normalize(st.dir);
-							const float k = 2.0f * dot(v, normal);
-							base = { fma(-k, normal.x, v.x), fma(-k, normal.y, v.y), fma(-k, normal.z, v.z) };
-							spread = shading.w;
 						}
 					}
 				}
@@ -945,8 +935,14 @@ namespace rt_hip
 						return; // (the lane stays free and asks again)
 					const uint32_t gy = global_row(ly, p);
 					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
-					st.fx = static_cast<float>(lx);
-					st.fy = static_cast<float>(gy);
+					{
+						const float fx = static_cast<float>(lx), fy = static_cast<float>(gy);
+						if (PINHOLE_ONLY || (!GENERAL_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
+							st.base = { fma(p.ray_d1[0], fx, fma(p.ray_d2[0], fy, p.ray_d0[0])), fma(p.ray_d1[1], fx, fma(p.ray_d2[1], fy, p.ray_d0[1])),
+										fma(p.ray_d1[2], fx, fma(p.ray_d2[2], fy, p.ray_d0[2])) };
+						else
+							st.base = { fx, fy, 0.0f };
+					}
 					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
 					const uint32_t first = chunk * item_samples, end = min(first + item_samples, p.samples_per_pixel);
@@ -1053,15 +1049,21 @@ namespace rt_hip
 				// stands at its sample's window — next_sample / start_item put it there — so both kinds of lane draw from
 				// st.counter and nothing is selected or multiplied per trip.)
 				{
-					RT_HIP_REGION(8); // the fused tail: two draws
-					// random draws (scatter: x, y of random_unit_vector, random.hpp:57-66; restart: the pixel jitter, :189)
+					RT_HIP_REGION(8); // the fused tail: one generator step
+					// ONE generator step for every lane (contract v4): a scattering lane's random<vec3>() (random_unit_vector,
+					// random.hpp:57-66: the third word follows below) or random<float>(), a restarting lane's random<vec2>() (the
+					// pixel jitter, :189).  As numerators k of u = k * 2^-24: the scaling is folded into the jitter's constants and
+					// cancels in the unit vector.
 					uint32_t counter = st.counter;
 					const uint32_t counter_at_start = counter;
-					// (as numerators k of u = k * 2^-24: the scaling folds into the jitter's fma and cancels in the unit vector)
-					float d0 = next_random_numerator(counter, st.keys);
-					float d1 = next_random_numerator(counter, st.keys);
+					uint32_t word = next_step_word(counter, st.keys);
+					uint32_t word_a = word * step_mul_a, word_b = word * step_mul_b;
+					float d0 = step_numerator(word_a);
+					float d1 = step_numerator(word_b);
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
-					bool unit_length = false; // `toward` is used as it is (sm's dielectric_scatter does not normalise)
+					// dot(toward, toward).  (sm's dielectric_scatter does not normalise what it returns: its lanes leave the 1 here,
+					// whose reciprocal square root is 1, and x * 1 is x for every x.)
+					float toward2 = 1.0f;
 					if (shade && SM && scatter_kind == scatter_dielectric)
 					{
 						// dielectric_scatter, sm_ray_tracer.cpp:181-219 (refract :161-172, schlick :174-179); shading.w = the
@@ -1092,9 +1094,8 @@ namespace rt_hip
 							const double x5 = (x2 * x2) * x;
 							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
 						}
-						st.counter = counter_at_start + st.keys.stride; // only d0 was consumed
+						st.counter = counter; // random<float>(): one step, its first draw
 						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
-						unit_length = true;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
 						st.origin = hit_pos;
 						const bool dead = st.bounces_left == 0; // the next trace() call would return {} at :157-158
@@ -1105,23 +1106,44 @@ namespace rt_hip
 					else if (shade)
 					{
 						RT_HIP_REGION(9); // scatter: third draw, unit vector, new direction
-						const bool metal = scatter_kind == scatter_metal;
-						float d2 = next_random_numerator(counter, st.keys);
-						while (d0 == 0.0f && d1 == 0.0f && d2 == 0.0f) // `if (p == zero) continue` (random.hpp:61-62)
+						uint32_t word_c = word * step_mul_c;
+						while (((word_a | word_b | word_c) >> 8) == 0u) // `if (p == zero) continue` (random.hpp:61-62): the next step
 						{
-							d0 = next_random_numerator(counter, st.keys);
-							d1 = next_random_numerator(counter, st.keys);
-							d2 = next_random_numerator(counter, st.keys);
+							word = next_step_word(counter, st.keys);
+							word_a = word * step_mul_a, word_b = word * step_mul_b, word_c = word * step_mul_c;
+							d0 = step_numerator(word_a);
+							d1 = step_numerator(word_b);
 						}
-						const vec3 u = normalize_unit_cube_numerators({ d0, d1, d2 });
-						// lambert: n + u (:117) == fma(1, u, n) exactly; metal: reflected + roughness * u (:133-134)
-						vec3 scatter = { fma(spread, u.x, base.x), fma(spread, u.y, base.y), fma(spread, u.z, base.z) };
+						const vec3 u = normalize_unit_cube_numerators({ d0, d1, step_numerator(word_c) });
+						vec3 scatter = normal + u; // lambert (:117)
 						bool absorbed = false;
-						if (metal)
+						if (scatter_kind == scatter_metal)
+						{
+							RT_HIP_REGION(5); // metal: normalise the incoming direction, reflect, spread by the roughness
+							// reflect(normalize(r.direction), n) + roughness * random_unit_vector() (:133-134, common.hpp:100-103)
+							const vec3 v = normalize(st.dir);
+							const float k = 2.0f * dot(v, normal);
+							const vec3 reflected = { fma(-k, normal.x, v.x), fma(-k, normal.y, v.y), fma(-k, normal.z, v.z) };
+							scatter = { fma(shading.w, u.x, reflected.x), fma(shading.w, u.y, reflected.y), fma(shading.w, u.z, reflected.z) };
 							absorbed = dot(scatter, normal) <= 0.0f; // (:135-136)
-						else if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon
-								 && __builtin_fabsf(scatter.z) <= approx_zero_epsilon)
-							scatter = normal; // (:118-119)
+							toward2 = dot(scatter, scatter);
+						}
+						else
+						{
+							toward2 = dot(scatter, scatter);
+							// `if (scatter.approx_zero()) scatter = normal` (:118-119): all three components within 1e-6 of zero.  Then the
+							// sum of their squares is at most 3e-12 (and a hair: three roundings) — a single comparison every lane can
+							// afford; the three of the rule itself run behind a vote that practically never fires.
+							if (__builtin_amdgcn_ballot_w64(toward2 <= 3.0001e-12f) != 0)
+							{
+								asm volatile("; lambert: some lane's scatter vector is next to zero" ::: "memory");
+								if (__builtin_fabsf(scatter.x) <= approx_zero_epsilon && __builtin_fabsf(scatter.y) <= approx_zero_epsilon && __builtin_fabsf(scatter.z) <= approx_zero_epsilon)
+								{
+									scatter = normal;
+									toward2 = dot(scatter, scatter);
+								}
+							}
+						}
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z }; // attenuation * trace(...) (:171)
 						st.origin = hit_pos;
 						toward = scatter;
@@ -1153,40 +1175,39 @@ namespace rt_hip
 								counter = counter_at_start;
 							}
 						}
-						const float px = fma(jx, random_scale, st.fx); // == fx + jx * 2^-24: the product is exact
-						const float py = fma(jy, random_scale, st.fy);
-						// rt's camera (w constant over the frame): near point and near-to-far vector are affine in (px, py) —
-						// contract v3, constants from the host.  Any other matrix goes through the per-sample division.  The LDS /
-						// big-scene kernels carry both forms; a scalar-register kernel is built for ONE of them (GC): as kernel
-						// arguments the two sets of 18 scalars together would cost its loop, which lives on its scalar
-						// registers, a spill per lane mask.
-						constexpr bool AFFINE_ONLY = NS > 0 && !GC, GENERAL_ONLY = NS > 0 && GC;
-						if (AFFINE_ONLY || (!GENERAL_ONLY && p.uniform_w)) // (wave-uniform: a kernel argument)
+						if (PINHOLE_ONLY || (!GENERAL_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
 						{
-							st.origin = { fma(p.ray_o1[0], px, fma(p.ray_o2[0], py, p.ray_o0[0])), fma(p.ray_o1[1], px, fma(p.ray_o2[1], py, p.ray_o0[1])),
-										  fma(p.ray_o1[2], px, fma(p.ray_o2[2], py, p.ray_o0[2])) };
-							toward = { fma(p.ray_d1[0], px, fma(p.ray_d2[0], py, p.ray_d0[0])), fma(p.ray_d1[1], px, fma(p.ray_d2[1], py, p.ray_d0[1])),
-									   fma(p.ray_d1[2], px, fma(p.ray_d2[2], py, p.ray_d0[2])) };
+							// rt's camera: the near-to-far vector from the pixel's base and the jitter, the near point from it (contract
+							// v4; constants from the host).  The LDS / big-scene kernels carry both forms; a scalar-register kernel is
+							// built for ONE of them (GC): as kernel arguments the two sets of scalars together would cost its loop, which
+							// lives on its scalar registers, a spill per lane mask.
+							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base.x)), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base.y)),
+									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base.z)) };
+							st.origin = { fma(p.ray_kappa, toward.x, p.ray_eye[0]), fma(p.ray_kappa, toward.y, p.ray_eye[1]), fma(p.ray_kappa, toward.z, p.ray_eye[2]) };
 						}
 						else
 						{
-							// un-project to depth 0 and depth 1 with the per-sample division (camera.hpp:42-48)
+							// any other matrix: un-project to depth 0 and depth 1 (camera.hpp:42-48) in homogeneous form, N and F.  The
+							// near point needs its division; the direction does not — far / F.w - near / N.w is F N.w - N F.w over
+							// N.w F.w, and normalize() removes a positive factor: one reciprocal per sample (round 4: two).
+							const float px = fma(jx, random_scale, st.base.x); // == x + jx * 2^-24: the product is exact
+							const float py = fma(jy, random_scale, st.base.y);
 							const float ndc_x = fma(px, p.sx, -1.0f);
 							const float ndc_y = fma(py, p.neg_sy, 1.0f);
-							float near_row[3], far_row[3];
+							float N[4], F[4];
 #pragma unroll
-							for (int r = 0; r < 3; r++)
+							for (int r = 0; r < 4; r++)
 							{
-								near_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
-								far_row[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
+								N[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_near[r]));
+								F[r] = fma(p.mx[r], ndc_x, fma(p.my[r], ndc_y, p.k_far[r]));
 							}
-							const float inv_wn = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_near[3])));
-							const float inv_wf = rcp_rn(fma(p.mx[3], ndc_x, fma(p.my[3], ndc_y, p.k_far[3])));
-							const vec3 near_pos = { near_row[0] * inv_wn, near_row[1] * inv_wn, near_row[2] * inv_wn };
-							const vec3 far_pos = { far_row[0] * inv_wf, far_row[1] * inv_wf, far_row[2] * inv_wf };
-							st.origin = near_pos;
-							toward = far_pos - near_pos; // vec3::direction(near, far) (:193)
+							const float inv_wn = rcp_rn(N[3]);
+							st.origin = { N[0] * inv_wn, N[1] * inv_wn, N[2] * inv_wn };
+							toward = { fma(F[0], N[3], -(N[0] * F[3])), fma(F[1], N[3], -(N[1] * F[3])), fma(F[2], N[3], -(N[2] * F[3])) };
+							if (N[3] * F[3] < 0.0f)
+								toward = { -toward.x, -toward.y, -toward.z };
 						}
+						toward2 = dot(toward, toward);
 						st.throughput = { 1.0f, 1.0f, 1.0f };
 						st.bounces_left = p.max_bounces - 1u;
 						st.counter = counter;
@@ -1194,14 +1215,9 @@ namespace rt_hip
 					}
 					if (shade || restart)
 					{
-						RT_HIP_REGION(11); // normalise the new direction
-						if (SM)
-						{
-							const vec3 unit = normalize(unit_length ? vec3{ 0.0f, 0.0f, 1.0f } : toward);
-							st.dir = unit_length ? toward : unit;
-						}
-						else
-							st.dir = normalize(toward);
+						RT_HIP_REGION(11); // normalise the new direction: toward * inv_sqrt(dot(toward, toward))
+						const float inv = inv_sqrt_rn(toward2);
+						st.dir = toward * inv;
 					}
 				}
 			}
@@ -1469,7 +1485,7 @@ namespace rt_hip
 	}
 
 #ifndef RT_HIP_FAST_BUILD
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool uniform_w)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
 		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
@@ -1478,7 +1494,6 @@ namespace rt_hip
 			return RT_HIP_KERNEL_TILED;
 		// up to 8 primitives: at least one sphere, at most three planes (round 4: neither a plane nor a camera whose w varies
 		// over the frame pushes a scene off this kernel any more)
-		(void)uniform_w;
 		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
@@ -1661,7 +1676,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.uniform_w != 0);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes,
@@ -1676,9 +1691,9 @@ namespace rt_hip
 		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * tile_slot_bytes(queue);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
-			const size_t lds_bytes = (2u * scalar_max_spheres + scalar_max_spheres / 4u) * sizeof(float4) + slot_bytes;
+			const size_t lds_bytes = 2u * scalar_max_spheres * sizeof(float4) + slot_bytes;
 #define RT_HIP_LAUNCH_SMALL(N, P)                                                                                                    \
-	(frame.uniform_w ? launch_queue<N, P, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)  \
+	(frame.pinhole ? launch_queue<N, P, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)  \
 					 : launch_queue<N, P, true>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream))
 #define RT_HIP_LAUNCH_SMALL_SPHERES(P, N_MAX)                                                                                        \
 	switch (scene.n_spheres)                                                                                                         \

@@ -67,19 +67,21 @@ namespace rt_hip
 		// row_r(depth) = fma(mx[r], ndc.x, fma(my[r], ndc.y, k[r])),  k_near[r] = fma(M[r][2], 0, M[r][3]),
 		// k_far[r] = fma(M[r][2], 1, M[r][3])
 		float mx[4], my[4], k_near[4], k_far[4];
-		// For a camera built as in camera.hpp:122-137 the last row of the inverse view-projection does not depend
-		// on x and y (M[3][0] = M[3][1] = 0), so w is a per-frame constant and 1/w can be taken once on the host.
-		// uniform_w != 0 says so; inv_w_* then hold 1.0f / k_*[3] (bit-identical to the per-sample division).
-		uint32_t uniform_w;
-		float inv_w_near, inv_w_far;
-		// Contract v3, primary rays of such a camera (uniform_w != 0): with w constant, the un-projected near point and
-		// the vector from it to the far point are AFFINE in the pixel position (px, py) — the per-frame constants are
-		// worked out once on the host in binary64 and rounded to binary32 (api.hip, primary_ray_constants; the oracle
-		// does the same): origin_c = fma(ray_o1[c], px, fma(ray_o2[c], py, ray_o0[c])), toward_c likewise from ray_d*.
-		// The scalar-register kernels read ONLY these; mx .. k_far above serve the preview and, in the LDS / big-scene
-		// kernels, a matrix whose w varies over the frame.
-		float ray_o0[3], ray_o1[3], ray_o2[3];
+		// Contract v4, primary rays.  For a camera built as in camera.hpp:122-137 the last row of the inverse view-projection
+		// does not depend on x and y, so w is a per-frame constant, the un-projected near and far points are AFFINE in the
+		// pixel position, and every near-to-far line passes through the eye: a PINHOLE.  pinhole != 0 says the matrix is one
+		// (decided on the host from binary64 constants, render.hip; the oracle has the same lines) and the kernels then use
+		//   base_c   = fma(ray_d1[c], x, fma(ray_d2[c], y, ray_d0[c]))          once per pixel (x, y: its column and row)
+		//   toward_c = fma(ray_j1[c], ka, fma(ray_j2[c], kb, base_c))           per sample; (ka, kb) = the jitter's numerators,
+		//                                                                        ray_j = ray_d * 2^-24
+		//   origin_c = fma(ray_kappa, toward_c, ray_eye[c])                     the near point: eye + near/(far-near) of the way
+		// The scalar-register kernels are built for ONE form; mx .. k_far above serve the preview and any other matrix (an
+		// orthographic or sheared frustum, a w that varies over the frame: the homogeneous form with one division per sample).
+		uint32_t pinhole;
 		float ray_d0[3], ray_d1[3], ray_d2[3];
+		float ray_j1[3], ray_j2[3];
+		float ray_eye[3];
+		float ray_kappa;
 	};
 
 	// the whole scene of the `small` kernel, passed by value as a kernel argument (-> SGPRs); host copy kept by the context
@@ -190,7 +192,7 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool uniform_w);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,

@@ -101,26 +101,46 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		f.k_near[r] = std::fmaf(M[r * 4 + 2], 0.0f, M[r * 4 + 3]);
 		f.k_far[r] = std::fmaf(M[r * 4 + 2], 1.0f, M[r * 4 + 3]);
 	}
-	// w = fma(mx[3], ndc.x, fma(my[3], ndc.y, k[3])) is exactly k[3] for every finite ndc when mx[3] and my[3] are
-	// (+-)0 and k[3] is not: then the per-sample 1/w is this one constant
-	f.uniform_w = (f.mx[3] == 0.0f && f.my[3] == 0.0f && f.k_near[3] != 0.0f && f.k_far[3] != 0.0f && std::isfinite(f.k_near[3]) && std::isfinite(f.k_far[3])) ? 1u : 0u;
-	f.inv_w_near = f.uniform_w ? 1.0f / f.k_near[3] : 0.0f;
-	f.inv_w_far = f.uniform_w ? 1.0f / f.k_far[3] : 0.0f;
-	if (f.uniform_w)
+	// Contract v4, primary rays (oracle/cpu_ref.cpp make_frame has the same lines).  w = fma(mx[3], ndc.x, fma(my[3], ndc.y,
+	// k[3])) is exactly k[3] for every finite ndc when mx[3] and my[3] are (+-)0 and k[3] is not; then
+	//   near(px, py) = (mx X + my Y + k_near) / w_near,   X = (2/W) px - 1,   Y = -(2/H) py + 1,
+	// is affine in the pixel position, and so is far - near.  rt's frustum is a pinhole's on top of that: every near-to-far
+	// line passes through the eye, near = eye + kappa (far - near) with one kappa for the frame.  The constants are worked
+	// out in binary64, in THIS order of operations, and rounded to binary32 once.  A matrix is taken as a pinhole's when the
+	// near point's motion per pixel is kappa times the near-to-far vector's to within 1e-5 (relative; 1e-10 of a pixel
+	// step: far below what binary32 resolves); anything else goes through the homogeneous form.
+	f.pinhole = 0u;
+	if (f.mx[3] == 0.0f && f.my[3] == 0.0f && f.k_near[3] != 0.0f && f.k_far[3] != 0.0f && std::isfinite(f.k_near[3]) && std::isfinite(f.k_far[3]))
 	{
-		// Contract v3, item 3 (oracle/cpu_ref.cpp make_frame has the same lines): with w constant over the frame,
-		//   near(px, py) = (mx X + my Y + k_near) / w_near,   X = (2/W) px - 1,   Y = -(2/H) py + 1,
-		// is affine in the pixel position, and so is far - near.  The constants are worked out in binary64, in THIS
-		// order of operations, and rounded to binary32 once; the kernels evaluate two fmas per component.
 		const double sx = 2.0 / static_cast<double>(width), sy = -(2.0 / static_cast<double>(height));
 		const double iwn = 1.0 / static_cast<double>(f.k_near[3]), iwf = 1.0 / static_cast<double>(f.k_far[3]);
+		double o0[3], o1[3], o2[3], d0[3], d1[3], d2[3];
 		for (int c = 0; c < 3; c++)
 		{
 			const double mx = f.mx[c], my = f.my[c], kn = f.k_near[c], kf = f.k_far[c];
-			const double o1 = mx * sx * iwn, o2 = my * sy * iwn, o0 = (kn - mx + my) * iwn;
+			o1[c] = mx * sx * iwn, o2[c] = my * sy * iwn, o0[c] = (kn - mx + my) * iwn;
 			const double e1 = mx * sx * iwf, e2 = my * sy * iwf, e0 = (kf - mx + my) * iwf;
-			f.ray_o0[c] = static_cast<float>(o0), f.ray_o1[c] = static_cast<float>(o1), f.ray_o2[c] = static_cast<float>(o2);
-			f.ray_d0[c] = static_cast<float>(e0 - o0), f.ray_d1[c] = static_cast<float>(e1 - o1), f.ray_d2[c] = static_cast<float>(e2 - o2);
+			d0[c] = e0 - o0[c], d1[c] = e1 - o1[c], d2[c] = e2 - o2[c];
+		}
+		const double dd = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2] + d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+		const double od = o1[0] * d1[0] + o1[1] * d1[1] + o1[2] * d1[2] + o2[0] * d2[0] + o2[1] * d2[1] + o2[2] * d2[2];
+		const double kappa = od / dd;
+		double worst = 0.0, scale = 0.0;
+		for (int c = 0; c < 3; c++)
+		{
+			worst = std::fmax(worst, std::fmax(std::fabs(o1[c] - kappa * d1[c]), std::fabs(o2[c] - kappa * d2[c])));
+			scale = std::fmax(scale, std::fmax(std::fabs(o1[c]), std::fabs(o2[c])));
+		}
+		if (dd > 0.0 && std::isfinite(kappa) && worst <= 1.0e-5 * scale) // (a NaN anywhere fails the comparison)
+		{
+			f.pinhole = 1u;
+			f.ray_kappa = static_cast<float>(kappa);
+			for (int c = 0; c < 3; c++)
+			{
+				f.ray_d0[c] = static_cast<float>(d0[c]), f.ray_d1[c] = static_cast<float>(d1[c]), f.ray_d2[c] = static_cast<float>(d2[c]);
+				f.ray_j1[c] = f.ray_d1[c] * 0x1.0p-24f, f.ray_j2[c] = f.ray_d2[c] * 0x1.0p-24f;
+				f.ray_eye[c] = static_cast<float>(o0[c] - kappa * d0[c]);
+			}
 		}
 	}
 
@@ -128,7 +148,7 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	rolling_buffers rolling;
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.uniform_w != 0);
+		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
 		queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes, variant == RT_HIP_KERNEL_STREAMED && ctx->scene.n_spheres >= sparse_launch_min_spheres);
@@ -400,6 +420,21 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 					delivery->abandon();
 			}
 		} staged{ nullptr };
+		// Declared AFTER `staged`, so that it runs FIRST on every early exit: whatever this call has put on the stream has
+		// drained before the staging frame is abandoned (wiped, or on growth unmapped, by the next begin()).  render_device can
+		// fail AFTER its kernel is enqueued (hipGetLastError, the timing events, the counters' copy): without this the device
+		// would go on storing pixels into a frame the zero-means-pending protocol has already handed to the next call — or
+		// into unmapped memory.  (multi.hip's settle_members is the same rule for several devices.)
+		struct drain_before_abandoning
+		{
+			hipStream_t stream;
+			bool armed;
+			~drain_before_abandoning()
+			{
+				if (armed && hipStreamSynchronize(stream) != hipSuccess)
+					(void)hipGetLastError();
+			}
+		} drain{ ctx->stream, false };
 		if (!d_frame)
 		{
 			if (const rt_hip_status st = delivery->begin(pixels_rgba8888, pixels, &d_frame))
@@ -412,9 +447,9 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 			RT_HIP_TRY(ctx->frame_rgb.reserve(rgb_bytes));
 			RT_HIP_TRY(ctx->staging_rgb.reserve(rgb_bytes));
 		}
+		drain.armed = true; // from here on the device may be storing into host memory: no return before the stream has drained
 		if (const rt_hip_status st = render_device(ctx, width, height, seed, flags & render_flag_mask, nullptr, d_frame, rgb_f32 ? ctx->frame_rgb.as<float>() : nullptr, ctx->stream, false, keep_stats, true))
 			return st;
-		// from here on the device may be storing into host memory: no return before the stream has drained
 		if (staged.delivery)
 			staged.delivery->launched();
 		hipError_t e = hipSuccess;
@@ -425,6 +460,7 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 			e = hipEventSynchronize(ctx->render_end);
 		const auto t0 = std::chrono::steady_clock::now();
 		const hipError_t drained = hipStreamSynchronize(ctx->stream);
+		drain.armed = drained != hipSuccess; // (a failed wait is tried once more on the way out)
 		RT_HIP_TRY(e);
 		RT_HIP_TRY(drained);
 		if (staged.delivery)

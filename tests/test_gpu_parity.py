@@ -84,7 +84,7 @@ def rays_for(scene_pod, width, height, n, rng):
     """Primary rays plus random secondary-like rays starting near surfaces."""
     origins, dirs = [], []
     for _ in range(n // 2):
-        o, d = oracle.primary_ray(scene_pod, width, height, rng.uniform(0, width), rng.uniform(0, height))
+        o, d = oracle.primary_ray(scene_pod, width, height, int(rng.integers(0, width)), int(rng.integers(0, height)), float(rng.integers(0, 1 << 24)), float(rng.integers(0, 1 << 24)))
         origins.append(o), dirs.append(d)
     o = rng.uniform(-3, 3, (n - n // 2, 3)).astype(np.float32)
     o[:, 1] = np.abs(o[:, 1])

@@ -12,7 +12,7 @@ import pytest
 
 import rt_amd
 from oracle import binding as oracle
-from tests.test_oracle_kat import M32, _stream_start
+from tests.test_oracle_kat import M32, _STEP_MULTIPLIERS, _stream_start
 
 MIN_HIT_DIST = 0.001  # mg_ray_tracer.cpp:20
 APPROX_ZERO = 1.0e-6  # muu's default epsilon for float (vector::approx_zero)
@@ -25,23 +25,27 @@ def column(pointer, n, dtype=np.float64):
 
 
 class Streams:
-    """one random stream per (pixel, sample): contract v2, numpy (tests/test_oracle_kat.py::_draws, one draw at a time)"""
+    """one random stream per (pixel, sample): contract v4, numpy (tests/test_oracle_kat.py::_draws, one generator step at a time).
+    A step serves one call of random<T>() and yields up to three numbers (src/random.hpp:37-46: components in brace-init order)."""
 
     def __init__(self, seed, pixels, samples):
         self.key, self.stride, self.counter = _stream_start(seed, pixels, samples)
 
-    def next(self, lanes):
+    def step(self, lanes, components):
         c = (self.counter[lanes] + self.stride[lanes]) & M32
         self.counter[lanes] = c
         x = c ^ (c >> np.uint64(16))
         x = (x * np.uint64(0x7FEB352D) + self.key[lanes]) & M32
         x ^= x >> np.uint64(15)
-        x = (x * np.uint64(0x846CA68B)) & M32
-        return (x >> np.uint64(8)).astype(np.float64) * 2.0**-24
+        return np.stack([(((x * m) & M32) >> np.uint64(8)).astype(np.float64) * 2.0**-24 for m in _STEP_MULTIPLIERS[:components]], axis=-1)
+
+    def next(self, lanes):
+        """random<float>()"""
+        return self.step(lanes, 1)[:, 0]
 
     def unit_vector(self, lanes):
         """random_unit_vector(), src/random.hpp:57-66: x, y, z in [0, 1), normalised (all zero: 2^-72, not handled here)"""
-        v = np.stack([self.next(lanes), self.next(lanes), self.next(lanes)], axis=-1)
+        v = self.step(lanes, 3)
         return v / np.linalg.norm(v, axis=-1, keepdims=True)
 
 
@@ -66,11 +70,11 @@ def render_f64(pod, width, height, seed, sm_materials=False):
     n = xs.size
     streams = Streams(seed, (ys * width + xs).astype(np.uint32), ss.astype(np.uint32))
     everyone = np.arange(n)
-    # `pos = screen_pos + (i ? random<vec2>() : vec2{0.5})` (:189): x drawn first; sample 0 draws nothing here
+    # `pos = screen_pos + (i ? random<vec2>() : vec2{0.5})` (:189): sample 0 draws nothing here
     later = everyone[ss > 0]
     jitter_x, jitter_y = np.full(n, 0.5), np.full(n, 0.5)
-    jitter_x[later] = streams.next(later)
-    jitter_y[later] = streams.next(later)
+    jitter = streams.step(later, 2)  # random<vec2>()
+    jitter_x[later], jitter_y[later] = jitter[:, 0], jitter[:, 1]
     px, py = xs + jitter_x, ys + jitter_y
 
     def screen_to_world(depth):  # camera.hpp:42-48

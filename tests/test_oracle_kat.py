@@ -4,6 +4,7 @@ The reference ships no tests or golden vectors ("parity unpinned"
 derived from the reference's SOURCE and computed independently of the oracle's code (closed forms, float64 numpy).
 """
 import math
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -11,6 +12,8 @@ import pytest
 import rt_amd
 from oracle import binding as oracle
 from tests.conftest import unpack
+
+ROOT = Path(__file__).resolve().parent.parent
 
 BLACK = 0x000000FF
 
@@ -61,6 +64,17 @@ def analytic_primary_direction(px, py, width, height, eye_dir=(0.0, 0.0, -1.0)):
     return d / np.linalg.norm(d)
 
 
+def pixel_and_jitter(p, size):
+    """a frame position as (pixel, jitter numerator): p = pixel + k * 2^-24 (contract v4 hands the jitter over as its numerator)"""
+    pixel = min(int(p), size - 1)
+    return pixel, float((p - pixel) * 2.0**24)
+
+
+def oracle_primary_ray_at(pod, width, height, px, py, **kw):
+    (x, ka), (y, kb) = pixel_and_jitter(px, width), pixel_and_jitter(py, height)
+    return oracle.primary_ray(pod, width, height, x, y, ka, kb, **kw)
+
+
 @pytest.mark.parametrize("size", [(256, 256), (1920, 1080), (64, 36), (7, 3)])
 def test_primary_rays_match_pinhole_model(size):
     width, height = size
@@ -68,7 +82,8 @@ def test_primary_rays_match_pinhole_model(size):
     pod = scene.describe(width, height)
     eye = np.array([0.0, 1.0, 3.0])
     for px, py in [(width / 2, height / 2), (0.0, 0.0), (width, height), (0.5, height - 0.5), (width * 0.25, height * 0.9)]:
-        o, d = oracle.primary_ray(pod, width, height, px, py)
+        o, d, pinhole = oracle_primary_ray_at(pod, width, height, px, py, want_form=True)
+        assert pinhole  # rt's camera, axis-aligned: the per-pixel base form
         want = analytic_primary_direction(px, py, width, height)
         # float32 inverse view-projection with near 0.01 / far 1000: ~1e-5 rad of direction error
         assert np.allclose(d, want, atol=5e-5), (px, py, d, want)
@@ -82,8 +97,11 @@ def test_primary_ray_for_rotated_camera():
     scene = rt_amd.Scene.named("basic").set_camera((1.0, 2.0, 3.0), (0.3, -0.2, -1.0))
     pod = scene.describe(320, 200)
     for px, py in [(160.0, 100.0), (10.5, 20.5), (300.0, 190.0)]:
-        _, d = oracle.primary_ray(pod, 320, 200, px, py)
-        assert np.allclose(d, analytic_primary_direction(px, py, 320, 200, (0.3, -0.2, -1.0)), atol=5e-5)
+        o, d = oracle_primary_ray_at(pod, 320, 200, px, py)
+        want = analytic_primary_direction(px, py, 320, 200, (0.3, -0.2, -1.0))
+        assert np.allclose(d, want, atol=5e-5)
+        off = o.astype(np.float64) - np.array([1.0, 2.0, 3.0])  # the near point: on the same eye ray, close to the eye
+        assert 0.005 < np.linalg.norm(off) < 0.03 and np.allclose(off / np.linalg.norm(off), want, atol=2e-3)
 
 
 # ---- visibility mask: max_bounces = 1 -> hit pixels are exactly black, miss pixels are the sky --------------------
@@ -265,17 +283,23 @@ def _stream_start(seed, pixels, samples):
     return key, stride, counter
 
 
+# contract v4: one generator step yields three draws — the mixed word times M2 * (1, A, A^2), top 24 bits of each product
+_M2 = 0x846CA68B
+_LATTICE = 0xADB4A92D  # Steele & Vigna's 32-bit LCG multiplier
+_STEP_MULTIPLIERS = [np.uint64(_M2), np.uint64(_M2 * _LATTICE & 0xFFFFFFFF), np.uint64(_M2 * _LATTICE * _LATTICE & 0xFFFFFFFF)]
+
+
 def _draws(key, stride, counter, n):
-    """first n draws of the streams starting at (key, stride, counter): float32[len(key), n]"""
+    """first n numbers of the streams starting at (key, stride, counter), steps flattened: float32[len(key), n]"""
     out = np.empty((len(key), n), dtype=np.float32)
     c = counter.copy()
-    for j in range(n):
+    for j in range(0, n, 3):
         c = (c + stride) & M32
         x = c ^ (c >> np.uint64(16))
         x = (x * np.uint64(0x7FEB352D) + key) & M32
         x ^= x >> np.uint64(15)
-        x = (x * np.uint64(0x846CA68B)) & M32
-        out[:, j] = (x >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)
+        for word, multiplier in enumerate(_STEP_MULTIPLIERS[: n - j]):
+            out[:, j + word] = (((x * multiplier) & M32) >> np.uint64(8)).astype(np.float32) * np.float32(2.0**-24)
     return out
 
 
@@ -356,6 +380,84 @@ def test_neighbouring_pixels_have_unrelated_streams():
     # lagged: the jitter draws of one pixel against the scatter draws of the next
     for lag in (1, 2, 3):
         assert abs(np.corrcoef(draws[:-1, lag:].ravel(), draws[1:, :-lag].ravel())[0, 1]) < 4.0 / np.sqrt(63 * (n - lag))
+
+
+# ---- contract v4: one generator step per random<T>() call ---------------------------------------------------------------
+def test_the_draws_of_a_step_fill_the_square_and_the_cube_evenly():
+    """The three draws of a step share one mixed word (they are its multiples by M2 (1, A, A^2)): each must still be uniform, and
+    so must the pairs and the triple — jitter positions and unit-cube points — at the resolution a frame can see."""
+    steps = oracle.random(1, 424242, 5, 3 * 120000).reshape(-1, 3).astype(np.float64)
+    across = np.array([oracle.random(9, p, 2, 3) for p in range(40000)], dtype=np.float64)  # the first step of 40 000 pixels
+    for points in (steps, across):
+        n = len(points)
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            counts, _, _ = np.histogram2d(points[:, i], points[:, j], bins=16, range=((0, 1), (0, 1)))
+            assert ((counts - n / 256) ** 2 / (n / 256)).sum() < 380  # 255 dof, p ~ 1e-6
+            assert abs(np.corrcoef(points[:, i], points[:, j])[0, 1]) < 5.0 / np.sqrt(n)
+        cells = (np.floor(points * 8).astype(int) * np.array([64, 8, 1])).sum(axis=1)
+        counts = np.bincount(cells, minlength=512)
+        assert ((counts - n / 512) ** 2 / (n / 512)).sum() < 680  # 511 dof, p ~ 1e-6
+    # the unit vectors made of them (random_unit_vector, random.hpp:57-66) cover the positive octant like independent draws do
+    unit = steps / np.linalg.norm(steps, axis=1, keepdims=True)
+    independent = np.random.default_rng(7).random((len(steps), 3))
+    independent /= np.linalg.norm(independent, axis=1, keepdims=True)
+    assert np.allclose(unit.mean(axis=0), independent.mean(axis=0), atol=4e-3)
+    assert np.allclose(np.cov(unit.T), np.cov(independent.T), atol=2e-3)
+
+
+def test_the_lattice_of_a_step_is_a_good_one():
+    """The triple of a step is a point of the lattice (1, A, A^2) / 2^32; tools/rng_lattice.py has the spectral test."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("rng_lattice", ROOT / "tools" / "rng_lattice.py")
+    lattice = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lattice)
+    assert lattice.IN_USE == _LATTICE
+    two, three = lattice.figures_of_merit(_LATTICE)
+    assert two > 0.95 and three > 0.9
+    assert lattice.figures_of_merit(_LATTICE * _LATTICE % (1 << 32))[0] > 0.85  # the first and third draw as a pair
+    assert lattice.figures_of_merit(65539)[1] < 0.1  # (the test does tell: RANDU's planes)
+
+
+def test_one_step_serves_one_call():
+    """random<vec2>() for the jitter, random<vec3>() per unit vector, random<float>() for sm's reflect-or-refract choice: the frame
+    of a scene with a metal, a lambert and a refracting sphere consumes exactly the steps the numpy restatement
+    (tests/test_independent_path_tracer.py) consumes — checked there pixel by pixel; here: the FIRST numbers of a sample's
+    stream are its jitter, as numerators of 2^-24."""
+    scene = rt_amd.Scene.named("basic").set_sampling(2, 1)  # one bounce: sample 1 consumes its jitter step and nothing else
+    pod = scene.describe(40, 30)
+    ka, kb = (float(v) * 2.0**24 for v in oracle.random(1, 17 * 40 + 11, 1, 2))
+    o, d = oracle.primary_ray(pod, 40, 30, 11, 17, ka, kb)
+    assert 0 <= ka < 2**24 and ka == int(ka) and 0 <= kb < 2**24 and kb == int(kb)
+    # the frame's pixel (11, 17) is the mean of the centre sample and of that jittered one: both miss or hit together with the rays
+    _, rgb, _ = oracle.render(pod, 40, 30, seed=1)
+    centre_o, centre_d = oracle.primary_ray(pod, 40, 30, 11, 17)
+    hits = [oracle.closest_hit(pod, np.array([a]), np.array([b]))[1][0] != 0 for a, b in ((centre_o, centre_d), (o, d))]
+    want = np.mean([np.zeros(3) if hit else oracle.sky(float(direction[1])) for hit, direction in zip(hits, (centre_d, d))], axis=0)
+    assert np.allclose(rgb[17, 11], want, rtol=1e-6)
+
+
+def test_a_camera_that_is_not_a_pinhole_takes_the_general_form_and_both_forms_agree():
+    scene = rt_amd.Scene.named("basic")
+    pod = scene.describe(320, 200)
+    pinhole = [oracle.primary_ray(pod, 320, 200, x, y, ka, kb, want_form=True) for x, y, ka, kb in ((0, 0, 0.0, 0.0), (160, 100, 2.0**23, 2.0**23), (319, 199, 2.0**24 - 1, 1.0))]
+    assert all(form for _, _, form in pinhole)
+    # the same matrix with a w row that says "x matters" by one part in 10^12: the homogeneous form, one division per sample
+    m = list(pod.inverse_view_projection)
+    m[12] = 1.0e-12 * m[15]
+    for i, v in enumerate(m):
+        pod.inverse_view_projection[i] = v
+    general = [oracle.primary_ray(pod, 320, 200, x, y, ka, kb, want_form=True) for x, y, ka, kb in ((0, 0, 0.0, 0.0), (160, 100, 2.0**23, 2.0**23), (319, 199, 2.0**24 - 1, 1.0))]
+    assert not any(form for _, _, form in general)
+    for (o1, d1, _), (o2, d2, _) in zip(pinhole, general):
+        assert np.allclose(d1, d2, atol=3e-7) and np.allclose(o1, o2, atol=3e-7)
+    # an orthographic frustum has a constant w and is no pinhole: parallel rays from different near points
+    ortho = rt_amd.Scene.named("basic").describe(320, 200)
+    for i, v in enumerate([2.0, 0, 0, 0, 0, 1.25, 0, 1.0, 0, 0, -10.0, 3.0, 0, 0, 0, 1.0]):
+        ortho.inverse_view_projection[i] = v
+    (o1, d1, f1), (o2, d2, f2) = (oracle.primary_ray(ortho, 320, 200, x, y, want_form=True) for x, y in ((10, 20), (300, 180)))
+    assert not f1 and not f2
+    assert np.array_equal(d1, d2) and np.allclose(d1, (0, 0, -1)) and not np.allclose(o1, o2)
 
 
 def test_seeds_that_differ_only_in_the_high_half_give_different_frames():

@@ -2,7 +2,8 @@
 """Generate tests/golden/*.npz from the CPU oracle (oracle/liboracle.so).
 
 The reference ships no golden vectors and cannot be run, so these fixtures are outputs of THIS
-project's oracle (arithmetic contract v3: per-pixel keyed random streams, single-step reciprocal square root).  They freeze the contract: a change to the
+project's oracle (arithmetic contract v4: per-pixel keyed random streams, one generator step per random<T>() call, single-step
+reciprocal square root, primary rays from a per-pixel base).  They freeze the contract: a change to the
 oracle or to the kernels that alters a single bit of any fixture is caught by tests/test_golden.py (CPU) and
 tests/test_gpu_parity.py (GPU).  Regenerate only together with a contract version bump.
 """

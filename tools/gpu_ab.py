@@ -15,7 +15,10 @@ if '_r3' in os.environ.get('RT_HIP_LIBRARY', ''):  # a round-3 build: bind what 
     capi.RT_HIP_SYMBOLS = [e for e in capi.RT_HIP_SYMBOLS if e[0] != 'rt_hip_live_frame_locks']
 flags = int('{os.environ.get("AB_FLAGS", "0")}')
 t = rt_amd.HipRayTracer(0)
-pod = (rt_amd.Scene.load('{scene}') if '{scene}'.endswith('.toml') else rt_amd.Scene.named('{scene}')).set_sampling({spp}).describe({w}, {h})
+scene_ = (rt_amd.Scene.load('{scene}') if '{scene}'.endswith('.toml') else rt_amd.Scene.named('{scene}')).set_sampling({spp})
+if os.environ.get('AB_TILT'):  # bench.py --tilt: a camera that is not axis-aligned (w varies over the frame: the general-camera kernels)
+    scene_.set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+pod = scene_.describe({w}, {h})
 t.upload(pod)
 frame = torch.empty(({h}, {w}), dtype=torch.int32, device='cuda:0')
 s = torch.cuda.current_stream().cuda_stream
