@@ -11,6 +11,11 @@ HIPFLAGS := --offload-arch=gfx950 -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fa
 HOSTFLAGS:= -std=c++20 -O2 -fPIC -Wall -Wextra
 
 HIPFLAGS += -fvisibility=hidden
+# No SLP vectorisation: it pairs the kernels' float arithmetic into v_pk_fma/mul/add_f32, which issue at half rate on this chip
+# (two of them cost what four plain instructions do, profiles/r04/valu_issue_costs.txt) and need their operands in even-aligned
+# register pairs — moves, and a higher register count.  Measured on the contract-v4 kernels: headline 2.28 -> 2.14 ms,
+# basic + plane 2.74 -> 2.62, tilted camera 2.80 -> 2.62 (profiles/r05/codegen_ab.txt).
+HIPFLAGS += -fno-slp-vectorize
 API_UNITS := context scene frame render multi group
 HIP_HDR  := rt_amd/csrc/kernels.hpp rt_amd/csrc/contract.hpp rt_amd/csrc/scan.hpp rt_amd/csrc/frame_group.hpp rt_amd/csrc/delivery.hpp rt_amd/csrc/internal.hpp include/rt_hip.h
 HOST_SRC := rt_amd/host/host_capi.cpp rt_amd/host/scene.cpp rt_amd/host/toml_subset.cpp

@@ -125,6 +125,40 @@ def cpu_baseline(scene_name: str, width: int, height: int, target_seconds: float
 
 
 PHASE_KEYS = ("render_ms", "gather_ms", "assemble_ms", "copy_ms", "host_issue_ms", "host_wait_ms")
+TILT = ((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))  # --tilt / the `interactive` leg: look down by 8.5 degrees from beside the scene's own eye point
+
+
+def process_cpu_seconds() -> float:
+    """CPU time of this process so far, all its threads (the module's carrier helpers included): user + system."""
+    import resource
+
+    usage = resource.getrusage(resource.RUSAGE_SELF)
+    return usage.ru_utime + usage.ru_stime
+
+
+def oracle_frame_digest(scene: str, width: int, height: int, spp: int, max_bounces: int, seed: int, tilt: bool):
+    """sha256 of the ORACLE's packed frame for this workload, from tests/golden/frame_digests.json (tools/gen_frame_digests.py:
+    made in the build container, minutes of CPU; the oracle does not run here) — None if the workload has no entry."""
+    try:
+        digests = json.loads((ROOT / "tests" / "golden" / "frame_digests.json").read_text())
+    except (OSError, ValueError):
+        return None
+    want = f"{scene} {width}x{height} {spp} spp max_bounces {max_bounces} seed {seed}" + (" tilt" if tilt else "")
+    for entry in digests.values():
+        if entry.get("workload") == want and not entry.get("partition"):
+            return entry
+    return None
+
+
+def frame_verdict(back_buffer, entry) -> dict:
+    """`frame_matches_oracle`: the frame the timed loop left in the caller's buffer against the oracle's digest."""
+    import hashlib
+
+    if entry is None:
+        return {"frame_matches_oracle": None, "frame_digest_source": "no entry for this workload in tests/golden/frame_digests.json"}
+    got = hashlib.sha256(back_buffer.tobytes()).hexdigest()
+    return {"frame_matches_oracle": got == entry["sha256"], "frame_sha256": got[:16],
+            "frame_digest_source": f"tests/golden/frame_digests.json (the oracle's frame, arithmetic contract {entry.get('contract')}, made by tools/gen_frame_digests.py); the buffer hashed is the one the timed steps rendered into"}
 
 
 def mean_phases(samples: list[dict]) -> dict:
@@ -132,6 +166,13 @@ def mean_phases(samples: list[dict]) -> dict:
     if not samples:
         return {}
     out = {k: round(sum(s[k] for s in samples) / len(samples), 4) for k in PHASE_KEYS}
+    if "carrier_bands" in samples[-1]:
+        # the default frame mode's carrier: bands of the frame, how many of them the helper threads had carried over before the
+        # stream drained (mean and the WORST step: a step whose helpers never ran shows as 0), helper threads
+        out["bands"] = samples[-1]["carrier_bands"]
+        out["bands_early"] = round(sum(s["carrier_bands_early"] for s in samples) / len(samples), 1)
+        out["bands_early_min"] = min(s["carrier_bands_early"] for s in samples)
+        out["helpers"] = samples[-1]["carrier_helpers"]
     out["transport"] = samples[-1]["transport"]
     out["scene_resident"] = int(all(s["scene_resident"] for s in samples))
     return out
@@ -163,8 +204,11 @@ def parse_args():
     ap.add_argument("--settle-ms", type=float, default=100.0, help="untimed GPU work before the W warm-up steps, so that the clocks have left idle when the timed region starts (an MI355X needs ~35 ms of load: profiles/r02/clock_ramp.txt); 0 disables")
     ap.add_argument("--no-kernel-only", action="store_true", help="skip the `kernel_only` and `plug_in_call` side legs (profiling runs: every render launch of the process is then a step of the drop-in loop)")
     ap.add_argument("--gather", default="library", choices=["library", "torch"], help="torchrun mode: `library` (default) = all three forms (see the docstring), `value` from the RCCL-gather form; `torch` = the torch form only")
-    ap.add_argument("--library-deadline-s", type=float, default=0.0, help="torchrun mode: seconds ONE form's child process may take before it is killed and reported as hung (0 = 180)")
+    ap.add_argument("--library-deadline-s", type=float, default=0.0, help="torchrun mode: seconds the `library` form's child process may take before it is killed and reported as hung (0 = 120); the side forms get 60 s each and the three together at most --forms-budget-s")
+    ap.add_argument("--forms-budget-s", type=float, default=300.0, help="torchrun mode: seconds all forms together may take; a side form that no longer fits is skipped (`status: skipped: budget`)")
     ap.add_argument("--form", default=None, choices=["library", "shared_frame", "torch"], help="(internal) this process is the child that runs one form; started by the torchrun-launched process")
+    ap.add_argument("--no-interactive", action="store_true", help="skip the `interactive` side leg (the reference's operating point: ground plane in, camera tilted, frames 16 ms apart)")
+    ap.add_argument("--frame-gap-ms", type=float, default=16.0, help="the `interactive` leg: host-side pause between two blocking calls (a 60 Hz caller that redraws on every frame; the GPU's clocks fall back in such gaps)")
     ap.add_argument("--direct-frame", action="store_true", help="single-process N > 1 only: RT_HIP_MULTI_DIRECT_FRAME — no gather, every GPU stores its pixels straight into the page-locked back buffer")
     ap.add_argument("--locked-frame", action="store_true", help="single-process only: time the opt-in zero-copy mode (RT_HIP_FLAG_PERSISTENT_FRAME: the caller's buffer itself page-locked and mapped) as `value` instead of the default delivery through the module's own frame")
     ap.add_argument("--same-device", action="store_true", help="single-process N > 1 only: put all N members on device 0 and move the stripes with peer copies (rehearsal on a one-GPU box; RCCL refuses duplicate devices)")
@@ -215,7 +259,7 @@ def make_build_line(args, pod, n_gpus, single_process):
         local_rows = local_rows_of(args.height, 0, n_gpus)
         scene_bytes = 20 * pod.n_spheres + 20 * pod.n_planes + 28 * pod.n_materials
         hbm_bytes = 4 * args.width * local_rows + scene_bytes
-        # Counter figures of this very workload (profiles/pmc_counters.json: rocprofv3 --pmc passes of tools/gpu_profile_r4.sh over
+        # Counter figures of this very workload (profiles/pmc_counters.json: rocprofv3 --pmc passes of tools/gpu_profile_run.sh over
         # this command), used only if they were measured on THESE kernels: the entry carries a hash of the kernel sources, and
         # a figure from other kernels is dropped, not reported.
         traffic = None
@@ -310,6 +354,60 @@ def make_build_line(args, pod, n_gpus, single_process):
     return build_line
 
 
+def interactive_leg(args, tracer, frame_flags) -> dict:
+    """Side key `interactive`: how rt is actually used.  It renders when the back buffer is dirty — the user moves the camera
+    (src/main.cpp:265-311, src/window.cpp:213-217) — so frames come a display interval apart, through a camera that is not
+    axis-aligned (its inverse view-projection carries rounding noise in w: the general-camera kernels), over the scene files as
+    a user has them: the ground plane of scenes/basic.toml:11-13 is one comment away.  Same size and sample count as the headline,
+    the blocking drop-in call in the default frame mode, `--frame-gap-ms` of host sleep between two calls (the GPU's clocks
+    fall back in the gaps).  Every figure is per call; the sleeps are not counted."""
+    import numpy as np
+
+    import rt_amd
+
+    scene = rt_amd.Scene.named("basic_plane").set_sampling(args.spp, args.max_bounces).set_camera(*TILT)
+    pod = scene.describe(args.width, args.height)
+    frame = np.zeros((args.height, args.width), dtype=np.uint32)
+    steps = max(1, min(args.steps, 30))
+    gap = args.frame_gap_ms * 1e-3
+    for _ in range(2):  # the scene change (fingerprint mismatch: one upload), the kernel's first launch
+        tracer.render(pod, args.width, args.height, seed=args.seed, flags=frame_flags, out=frame)
+        time.sleep(gap)
+    wall_ms, kernel_ms = [], []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        stats = tracer.render(pod, args.width, args.height, seed=args.seed, flags=frame_flags, out=frame)[2]
+        wall_ms.append((time.perf_counter() - t0) * 1e3)
+        kernel_ms.append(stats["render_ms"])
+        time.sleep(gap)
+    # the same frames back to back (no gaps): what the clocks cost
+    busy = []
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        tracer.render(pod, args.width, args.height, seed=args.seed, flags=frame_flags, out=frame)
+        busy.append((time.perf_counter() - t0) * 1e3)
+    samples = args.width * args.height * args.spp
+    flops = algorithmic_flops(stats["primary_samples"], stats["segments"], pod.n_spheres, pod.n_planes)
+    mean_wall, mean_kernel = sum(wall_ms) / steps, sum(kernel_ms) / steps
+    out = {
+        "workload": f"scenes/basic_plane.toml (basic.toml with its commented ground plane) {args.width}x{args.height} {args.spp} spp, camera tilted (eye {TILT[0]}, looking along {TILT[1]}), one blocking call every {args.frame_gap_ms:g} ms + its own duration",
+        "steps": steps,
+        "ms_per_step": round(mean_wall, 4),
+        "ms_per_step_min": round(min(wall_ms), 4),
+        "ms_per_step_max": round(max(wall_ms), 4),
+        "value": round(samples / (mean_wall * 1e-3) / 1e6, 1),
+        "unit": "Mrays/s",
+        "kernel_ms": round(mean_kernel, 4),
+        "kernel": stats["kernel"],
+        "back_to_back_ms_per_step": round(sum(busy) / steps, 4),
+        "roofline_frac": round(flops / (mean_kernel * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+        "mean_segments_per_sample": round(stats["segments"] / max(stats["primary_samples"], 1), 4),
+        "what": "the drop-in call as the plug-in's user sees it between two redraws; not `value` (BASELINE.json's metric is the plane-less, axis-aligned frame)",
+    }
+    out.update(frame_verdict(frame, oracle_frame_digest("basic_plane", args.width, args.height, args.spp, args.max_bounces, args.seed, True)))
+    return out
+
+
 def main() -> None:
     args = parse_args()
     single_process = "RANK" not in os.environ  # not launched by torchrun: one process drives all --gpus devices itself
@@ -335,7 +433,7 @@ def single_process_main(args) -> None:
     torch.cuda.set_device(device)
     scene = rt_amd.Scene.named(args.scene).set_sampling(args.spp, args.max_bounces)
     if args.tilt:
-        scene.set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
+        scene.set_camera(*TILT)
     pod = scene.describe(args.width, args.height)
     flags = capi.RT_HIP_FLAG_FORCE_TILED if args.tiled else (capi.RT_HIP_FLAG_FORCE_STREAMED if args.streamed else (capi.RT_HIP_FLAG_FORCE_RESIDENT if args.resident else 0))
     if args.fast:
@@ -381,6 +479,7 @@ def single_process_main(args) -> None:
         member_kernel_ms = [0.0] * n_gpus
         phase_samples = []
         readback_ms_sum = 0.0
+        cpu0 = process_cpu_seconds()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             stats = step()  # blocking: returns with the frame in back_buffer
@@ -394,14 +493,20 @@ def single_process_main(args) -> None:
             phase_samples.append(tracer.phases())
         fence()
         elapsed = time.perf_counter() - t0
+        host_cpu_ms_per_step = (process_cpu_seconds() - cpu0) / args.steps * 1e3
         member0 = tracer.member_stats(0) if n_gpus > 1 else stats
         per_rank_kernel_ms = [v / args.steps for v in member_kernel_ms]
         phases = mean_phases(phase_samples)
         transport = phases.get("transport", "none")
         extras["drop_in_breakdown"] = dict(
-            {"kernel_ms": round(per_rank_kernel_ms[0], 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(elapsed / args.steps * 1e3, 4), "first_call_ms": round(first_call_ms, 3)},
-            **{k: phases[k] for k in PHASE_KEYS if k in phases},
+            {"kernel_ms": round(per_rank_kernel_ms[0], 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(elapsed / args.steps * 1e3, 4), "first_call_ms": round(first_call_ms, 3),
+             # CPU time the whole process spent per step, ALL threads (getrusage): the caller's thread waiting in the call plus, in
+             # the default frame mode, the module's helper threads polling the frame while it is traced
+             "host_cpu_ms_per_step": round(host_cpu_ms_per_step, 4)},
+            **{k: phases[k] for k in (*PHASE_KEYS, "bands", "bands_early", "bands_early_min", "helpers") if k in phases},
         )
+        if n_gpus == 1 and not (args.tiled or args.streamed or args.resident or args.fast):
+            extras.update(frame_verdict(back_buffer, oracle_frame_digest(args.scene, args.width, args.height, args.spp, args.max_bounces, args.seed, args.tilt)))
         if n_gpus > 1:
             infos = [tracer.comm_info(r) for r in range(n_gpus)]
             extras["rccl"] = {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_member": [i["rank"] for i in infos], "transport": transport, "source": "ncclCommCount / ncclCommUserRank / ncclCommCuDevice per member" if transport == "rccl_gather" else "no communicator (this transport does not use RCCL)"}
@@ -421,14 +526,16 @@ def single_process_main(args) -> None:
             other_buffer = np.zeros((args.height, args.width), dtype=np.uint32)
             for _ in range(3):
                 tracer.render(pod, args.width, args.height, seed=args.seed, flags=other_flags, out=other_buffer, stats=False)
+            cpu1 = process_cpu_seconds()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 tracer.render(pod, args.width, args.height, seed=args.seed, flags=other_flags, out=other_buffer, stats=False)
             per_frame = (time.perf_counter() - t1) / args.steps
+            other_cpu_ms = (process_cpu_seconds() - cpu1) / args.steps * 1e3
             same_frame = bool(np.array_equal(other_buffer, back_buffer))
             tracer.forget_frame()
             extras["other_frame_mode"] = {"mode": "default (module-owned frame + host carrier threads)" if args.locked_frame else "locked (RT_HIP_FLAG_PERSISTENT_FRAME: the caller's buffer page-locked and mapped, zero copy; opt-in)",
-                                          "ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "vs_plug_in_call_ms": round(per_frame * 1e3 - plug_in_call["ms_per_step"], 4), "same_frame": same_frame,
+                                          "ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "vs_plug_in_call_ms": round(per_frame * 1e3 - plug_in_call["ms_per_step"], 4), "same_frame": same_frame, "host_cpu_ms_per_step": round(other_cpu_ms, 4),
                                           "what": "rt_hip_render with stats == NULL in the other frame mode, same scene and seed"}
             # side figure: kernel-only rate (scene resident, frame left in HBM, launches back to back)
             frame = torch.empty((args.height, args.width), dtype=torch.int32, device=f"cuda:{device}")
@@ -442,6 +549,8 @@ def single_process_main(args) -> None:
             torch.cuda.synchronize()
             per_frame = (time.perf_counter() - t1) / args.steps
             kernel_only = {"ms_per_step": round(per_frame * 1e3, 4), "value": round(samples_total / per_frame / 1e6, 1), "unit": "Mrays/s", "what": "scene resident, frame left in HBM, launches back to back (no host frame)"}
+        if n_gpus == 1 and not args.no_kernel_only and not args.no_interactive and not (args.tiled or args.streamed or args.resident or args.fast):
+            extras["interactive"] = interactive_leg(args, tracer, capi.RT_HIP_FLAG_PERSISTENT_FRAME if args.locked_frame else 0)
         tracers = [tracer]
         parallelism = "1 GPU" if n_gpus == 1 else f"ONE process, {n_gpus} GPUs behind rt_hip_render: row stripes of 8, transport {transport}"
 
@@ -703,13 +812,38 @@ def forms_parent_main(args) -> None:
     pod = scene.describe(args.width, args.height)  # (host library only)
     samples_total = args.width * args.height * args.spp
     build_line = make_build_line(args, pod, n_gpus, False)
-    deadline = args.library_deadline_s or 180.0
     forms = ["torch"] if args.gather == "torch" else list(FORMS)
+    # The form north_star names runs FIRST and its line is printed as soon as it is done; the side forms then add their
+    # figures to `paths` in a second, final line.  Every form has a deadline of its own (the one `value` comes from 120 s,
+    # the side forms 60 s) and all together a budget (300 s): a driver that allows the benchmark ten minutes sees a line even
+    # if every form after the first hangs.
+    first_deadline = args.library_deadline_s or 120.0
+    side_deadline = min(60.0, first_deadline)
+    started = time.monotonic()
+
+    def make_line(chosen, final):
+        outcome = results[chosen]
+        in_flight = outcome.get("frames_in_flight", 1)
+        more = dict(outcome["extras"], paths=dict(paths), value_from=chosen, per_rank=spread(outcome["kernels"]) if in_flight == 1 else None)
+        if "rccl" not in more:
+            more["rccl"] = {"ranks": world, "devices": None, "transport": outcome["transport_text"], "source": "torch.distributed's process group (the module's own communicator was not used)"}
+        line = build_line(chosen, outcome["elapsed"], outcome["kernels"], outcome["member0"], f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {outcome['transport_text']}", more)
+        line["config"]["frames_in_flight"] = in_flight
+        line["line"] = "final" if final else f"early: printed when the `{chosen}` form was done; a final line with the side forms' `paths` follows"
+        return line
 
     paths: dict = {}
     results: dict = {}
     any_hung = False
-    for form in forms:
+    early_line_from = None
+    for index, form in enumerate(forms):
+        deadline = first_deadline if index == 0 else side_deadline
+        verdict = [index == 0 or args.forms_budget_s - (time.monotonic() - started) >= deadline]
+        dist.broadcast_object_list(verdict, src=0)  # (rank 0's clock decides for everybody)
+        if not verdict[0]:
+            if rank == 0:
+                paths[form] = {"status": f"skipped: budget ({args.forms_budget_s - (time.monotonic() - started):.0f} s of {args.forms_budget_s:.0f} s left, the form may take {deadline:.0f} s)"}
+            continue
         ports = [None]
         if rank == 0:
             with socket.socket() as s:
@@ -755,6 +889,9 @@ def forms_parent_main(args) -> None:
                 results[form] = outcome
                 paths[form] = {"status": "ok", "ms_per_step": round(outcome["elapsed"] / args.steps * 1e3, 4), "value": round(samples_total * args.steps / outcome["elapsed"] / 1e6, 1),
                                "per_rank": spread(outcome["kernels"]) if outcome.get("frames_in_flight", 1) == 1 else None, "transport": outcome["transport_text"] if form == "torch" else outcome["extras"]["rccl"]["transport"]}
+            if index == 0 and form in results and len(forms) > 1:
+                print(json.dumps(make_line(form, final=False)), flush=True)
+                early_line_from = form
 
     exit_code = 3 if any_hung else 0
     if rank == 0:
@@ -766,13 +903,9 @@ def forms_parent_main(args) -> None:
                               "status": "no form produced a result", "paths": paths}), flush=True)
             exit_code = exit_code or 4
         else:
-            outcome = results[chosen]
-            in_flight = outcome.get("frames_in_flight", 1)
-            more = dict(outcome["extras"], paths=paths, value_from=chosen, per_rank=spread(outcome["kernels"]) if in_flight == 1 else None)
-            if "rccl" not in more:
-                more["rccl"] = {"ranks": world, "devices": None, "transport": outcome["transport_text"], "source": "torch.distributed's process group (the module's own communicator was not used)"}
-            line = build_line(chosen, outcome["elapsed"], outcome["kernels"], outcome["member0"], f"one process per GPU, {n_gpus} GPUs: row stripes of 8, {outcome['transport_text']}", more)
-            line["config"]["frames_in_flight"] = in_flight
+            line = make_line(chosen, final=True)
+            if early_line_from:
+                line["early_line_from"] = early_line_from
             print(json.dumps(line), flush=True)
     dist.barrier()
     dist.destroy_process_group()

@@ -25,8 +25,11 @@
 extern "C" {
 #endif
 
-#define RT_HIP_ABI_VERSION 5u /* frozen: additions only (round 4 added rt_hip_live_frame_locks; the known-answer hooks of
-                               * rounds 1-3 moved to the test-only library, include/rt_hip_kat.h) */
+/* 6 (round 5): arithmetic contract v4 — the same entry points, DIFFERENT frames for a given seed — and three more words at the
+ * end of rt_hip_phases.  5 (round 4): rt_hip_live_frame_locks added; the known-answer hooks of rounds 1-3 moved to the test-only
+ * library (include/rt_hip_kat.h); rt_hip_render without RT_HIP_FLAG_PERSISTENT_FRAME delivers through the module's own frame.
+ * A consumer checks rt_hip_abi_version() against the header it was compiled with. */
+#define RT_HIP_ABI_VERSION 6u
 
 /* librt_hip.so is built with hidden visibility: these entry points are ALL it exports. */
 #if defined(__GNUC__)
@@ -411,6 +414,15 @@ typedef struct rt_hip_phases
 	float host_wait_ms;	 /* host wall time blocked until the frame was complete */
 	uint32_t transport;	 /* RT_HIP_TRANSPORT_* that this frame took */
 	uint32_t scene_resident; /* 1: the columns' fingerprint matched, nothing was uploaded */
+	/* ABI 6.  The default frame mode (module-owned page-locked frame + host carrier threads): how the frame reached the caller's
+	 * buffer.  carrier_bands = 64 KB bands the frame was carried in (0: the kernels stored straight into the caller's page-locked
+	 * buffer, or a multi-GPU / preview path); carrier_bands_early = of those, carried over BEFORE the stream had drained — by
+	 * the helper threads, while the frame was being traced; carrier_helpers = helper threads the context runs (0: the caller's own
+	 * thread carries everything after the kernel).  A frame whose carrier_bands_early is 0 although carrier_helpers is not was
+	 * carried by the caller's thread alone: the helpers never got to run (frame delivery). */
+	uint32_t carrier_bands;
+	uint32_t carrier_bands_early;
+	uint32_t carrier_helpers;
 } rt_hip_phases;
 RT_HIP_API rt_hip_status rt_hip_phases_fetch(rt_hip_ctx* ctx, rt_hip_phases* out_phases);
 

@@ -41,6 +41,8 @@
 //                            transform_position); origin = N.xyz * (1.0f / N.w); toward_c = fmaf(F_c, N.w, -(N_c * F.w)),
 //                            negated if N.w * F.w < 0 — far/F.w - near/N.w times the positive factor |N.w F.w|, which
 //                            normalize() removes: one division per sample instead of two.
+//   ray-plane distance      : t = -(n.o + d) * (1.0f / (n.dir)) — the reciprocal correctly rounded, then one product (the
+//                            reference's build lets its compiler do the same: -ffast-math implies -freciprocal-math).
 //   pixel sum               : samples are added in CHUNKS of 16 consecutive samples (each chunk summed in sample
 //                            order, starting from 0), and the chunk sums are added in chunk order (left fold starting
 //                            from the first chunk's sum).  For spp <= 16 this is the reference's plain sequential
@@ -419,7 +421,7 @@ namespace
 		if (std::fabs(den) <= approx_zero_epsilon)
 			return false;
 		const float num = dot(n, r.origin) + d;
-		t = (-num) / den;
+		t = (-num) * (1.0f / den);
 		if (t < 0.0f)
 			return false;
 		return true;

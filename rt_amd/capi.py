@@ -16,7 +16,7 @@ from pathlib import Path
 
 LIB_DIR = Path(__file__).resolve().parent / "lib"
 
-RT_HIP_ABI_VERSION = 5
+RT_HIP_ABI_VERSION = 6
 RT_HIP_DEFAULT_STRIPE_ROWS = 8
 RT_HIP_FLAG_FORCE_TILED = 1 << 0
 RT_HIP_FLAG_FORCE_RESIDENT = 1 << 1
@@ -123,6 +123,9 @@ class RtHipPhases(C.Structure):
         ("host_wait_ms", C.c_float),
         ("transport", C.c_uint32),
         ("scene_resident", C.c_uint32),
+        ("carrier_bands", C.c_uint32),
+        ("carrier_bands_early", C.c_uint32),
+        ("carrier_helpers", C.c_uint32),
     ]
 
     def as_dict(self) -> dict:

@@ -322,7 +322,7 @@ namespace rt_hip
 		if (__builtin_fabsf(den) <= approx_zero_epsilon)
 			return false;
 		const float num = dot(n, o) + pd;
-		t = (-num) / den;
+		t = (-num) * rcp_rn(den); // (contract v4: the correctly rounded reciprocal, then one product)
 		if (t < 0.0f)
 			return false;
 		return true;

@@ -57,6 +57,7 @@ namespace rt_hip
 		unsigned helpers() const { return static_cast<unsigned>(threads_.size()); }
 		// (tests, RT_HIP_DEBUG_FRAME) bands of the last frame that were complete before finish() was called
 		size_t early_bands() const { return early_bands_; }
+		size_t bands() const { return bands_; } // of the frame begun last
 
 	  private:
 		enum : uint32_t { storing = 0, drained = 1, abandoned = 2 };

@@ -203,13 +203,21 @@ namespace rt_hip
 			return true;
 		}
 
+#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE
+		constexpr uint32_t small_table_float4s = 2u * scalar_max_spheres + scalar_max_spheres / 4u;
+#else
+		constexpr uint32_t small_table_float4s = 2u * scalar_max_spheres; // LDS tables of the scalar-register kernels: geometry, shading
+#endif
+
 		// everything a lane carries between loop trips
 		struct lane_state
 		{
 			vec3 origin, dir;	// current ray
 			vec3 throughput;	// product of attenuations so far (trace unrolled front to back)
 			vec3 chunk_sum;		// running sum of the chunk of samples in flight (:186,193)
-			vec3 base;			// pinhole camera: the near-to-far vector through the pixel's corner (frame_params); any other: (x, y, -) of the pixel
+			// what a pixel's samples start from (frame_params): pinhole camera — the near-to-far vector through the pixel's
+			// corner; any other matrix — (x, y, -) of the pixel
+			float base[3];
 			stream_keys keys;	// random streams of the pixel (contract.hpp): the key of its hash function and its counter stride
 			uint32_t counter;	// random stream position
 			// The samples of an item, counted in STREAM POSITIONS: a sample's window starts at stride * (index << 12)
@@ -451,7 +459,7 @@ namespace rt_hip
 			// [NS > 0] 8 geometry (with the scatter function) + 8 shading float4s | [NS == 0] all primitives; then the chunk slots
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
-			const uint32_t table_float4s = NS > 0 ? 2 * scalar_max_spheres : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
+			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -463,6 +471,9 @@ namespace rt_hip
 						// scalar registers — the scatter function: ONE 16-byte read for both)
 						lds_geometry[i] = make_float4(small.geometry[i].x, small.geometry[i].y, small.geometry[i].z, __uint_as_float(small.scatter[i]));
 						lds_shading[i] = small.shading[i];
+#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE
+						reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres)[i] = small.scatter[i];
+#endif
 					}
 				}
 			}
@@ -837,28 +848,44 @@ namespace rt_hip
 					}
 					else if (NS > 0)
 					{
-						// all NS discriminants first (independent straight-line code with scalar operands), one branch for
-						// "no lane can hit anything", then the square-root halves in index order
+						// The discriminants of a GROUP of spheres first (independent straight-line code with scalar operands), one
+						// branch for "no lane can hit any of them", then their square-root halves in index order.  Up to four spheres
+						// are one group.  From five spheres on they go in groups of four: every discriminant of a group is three live
+						// vector registers until its square-root half has run, and seven or eight at once put the kernel over its
+						// budget (72 at 7 waves per SIMD) — round 4 lived with 12-16 bytes of scratch there; in round 5 the same source
+						// took 84-124 bytes with the contract-v4 tail, and dielectric.toml went from 2.7 to 9.4 ms
+						// (profiles/r05/codegen_ab.txt; tools/kernel_registers.py lists every build's registers and scratch).
 						candidate best = { 0.0f, 0u, false };
-						constexpr int slots_ns = NS > 0 ? NS : 1; // (this branch is compiled, though never taken, for NS <= 0)
-						sphere_probe probes[slots_ns];
-						unsigned long long lanes[slots_ns];
-						unsigned long long any_lane = 0;
+						constexpr int spheres_ns = NS > 0 ? NS : 1; // (this branch is compiled, though never taken, for NS <= 0)
+#ifdef RT_HIP_PROBE_GROUP
+						constexpr int group = RT_HIP_PROBE_GROUP; // (A/B builds)
+#else
+						constexpr int group = spheres_ns <= 4 ? spheres_ns : 4;
+#endif
 #pragma unroll
-						for (int i = 0; i < NS; i++)
+						for (int first = 0; first < NS; first += group)
 						{
-							probes[i] = probe_sphere(st.origin, st.dir, small.geometry[i]); // SGPR operands
-							lanes[i] = __builtin_amdgcn_ballot_w64(probes[i].pos);
-							any_lane |= lanes[i];
-						}
-						if (any_lane != 0)
-						{
+							sphere_probe probes[group];
+							unsigned long long lanes[group];
+							unsigned long long any_lane = 0;
 #pragma unroll
-							for (int i = 0; i < NS; i++)
+							for (int i = 0; i < group; i++)
+								if (first + i < NS)
+								{
+									probes[i] = probe_sphere(st.origin, st.dir, small.geometry[first + i]); // SGPR operands
+									lanes[i] = __builtin_amdgcn_ballot_w64(probes[i].pos);
+									any_lane |= lanes[i];
+								}
+							if (any_lane != 0)
 							{
-								if (lanes[i] != 0)
-									RT_HIP_REGION(2); // square-root half of one sphere
-								finish_sphere(best, probes[i], small.geometry[i].w, static_cast<uint32_t>(i), lanes[i]);
+#pragma unroll
+								for (int i = 0; i < group; i++)
+									if (first + i < NS)
+									{
+										if (lanes[i] != 0)
+											RT_HIP_REGION(2); // square-root half of one sphere
+										finish_sphere(best, probes[i], small.geometry[first + i].w, static_cast<uint32_t>(first + i), lanes[i]);
+									}
 							}
 						}
 						if (NP > 0)
@@ -914,10 +941,21 @@ namespace rt_hip
 							RT_HIP_REGION(3); // hit: lookups + normal
 							const float4 g = lds_geometry[small_index];
 							shading = lds_shading[small_index];
+#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE // (A/B build, profiles/r05: the scatter function as a word of its own behind the shading table)
+							scatter_kind = reinterpret_cast<const uint32_t*>(lds + 2 * scalar_max_spheres)[small_index];
+#else
 							scatter_kind = __float_as_uint(g.w);
-							normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
+#endif
 							if (NP > 0 && kind == 2u)
 								normal = { g.x, g.y, g.z }; // the plane's normal as it is, not flipped toward the ray (:58)
+							else
+							{
+								// (a branch, not a select: a wave whose hits are all on the ground plane — most of a frame's — skips the
+								// normalisation altogether)
+								if (NP > 0)
+									asm volatile("; hit: some lane hit a sphere" ::: "memory");
+								normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
+							}
 						}
 					}
 				}
@@ -938,10 +976,13 @@ namespace rt_hip
 					{
 						const float fx = static_cast<float>(lx), fy = static_cast<float>(gy);
 						if (PINHOLE_ONLY || (!GENERAL_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
-							st.base = { fma(p.ray_d1[0], fx, fma(p.ray_d2[0], fy, p.ray_d0[0])), fma(p.ray_d1[1], fx, fma(p.ray_d2[1], fy, p.ray_d0[1])),
-										fma(p.ray_d1[2], fx, fma(p.ray_d2[2], fy, p.ray_d0[2])) };
+						{
+#pragma unroll
+							for (int c = 0; c < 3; c++)
+								st.base[c] = fma(p.ray_d1[c], fx, fma(p.ray_d2[c], fy, p.ray_d0[c]));
+						}
 						else
-							st.base = { fx, fy, 0.0f };
+							st.base[0] = fx, st.base[1] = fy, st.base[2] = 0.0f;
 					}
 					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
@@ -1181,8 +1222,8 @@ namespace rt_hip
 							// v4; constants from the host).  The LDS / big-scene kernels carry both forms; a scalar-register kernel is
 							// built for ONE of them (GC): as kernel arguments the two sets of scalars together would cost its loop, which
 							// lives on its scalar registers, a spill per lane mask.
-							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base.x)), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base.y)),
-									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base.z)) };
+							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base[0])), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base[1])),
+									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base[2])) };
 							st.origin = { fma(p.ray_kappa, toward.x, p.ray_eye[0]), fma(p.ray_kappa, toward.y, p.ray_eye[1]), fma(p.ray_kappa, toward.z, p.ray_eye[2]) };
 						}
 						else
@@ -1190,8 +1231,8 @@ namespace rt_hip
 							// any other matrix: un-project to depth 0 and depth 1 (camera.hpp:42-48) in homogeneous form, N and F.  The
 							// near point needs its division; the direction does not — far / F.w - near / N.w is F N.w - N F.w over
 							// N.w F.w, and normalize() removes a positive factor: one reciprocal per sample (round 4: two).
-							const float px = fma(jx, random_scale, st.base.x); // == x + jx * 2^-24: the product is exact
-							const float py = fma(jy, random_scale, st.base.y);
+							const float px = fma(jx, random_scale, st.base[0]); // == x + jx * 2^-24: the product is exact
+							const float py = fma(jy, random_scale, st.base[1]);
 							const float ndc_x = fma(px, p.sx, -1.0f);
 							const float ndc_y = fma(py, p.neg_sy, 1.0f);
 							float N[4], F[4];
@@ -1691,7 +1732,7 @@ namespace rt_hip
 		const size_t slot_bytes = big_scene ? 0u : static_cast<size_t>(block_threads / 64u) * tile_slot_bytes(queue);
 		if (variant == RT_HIP_KERNEL_SMALL)
 		{
-			const size_t lds_bytes = 2u * scalar_max_spheres * sizeof(float4) + slot_bytes;
+			const size_t lds_bytes = small_table_float4s * sizeof(float4) + slot_bytes;
 #define RT_HIP_LAUNCH_SMALL(N, P)                                                                                                    \
 	(frame.pinhole ? launch_queue<N, P, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream)  \
 					 : launch_queue<N, P, true>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream))

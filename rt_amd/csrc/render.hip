@@ -466,6 +466,9 @@ extern "C" rt_hip_status rt_hip_render(rt_hip_ctx* ctx,
 		if (staged.delivery)
 		{
 			staged.delivery->finish(); // the last tiles' pixels; returns with the whole frame in the caller's buffer
+			ctx->phases.carrier_bands = static_cast<uint32_t>(staged.delivery->carrier.bands());
+			ctx->phases.carrier_bands_early = static_cast<uint32_t>(staged.delivery->carrier.early_bands());
+			ctx->phases.carrier_helpers = staged.delivery->carrier.helpers();
 			staged.delivery = nullptr;
 		}
 		if (rgb_f32)

@@ -61,29 +61,32 @@ namespace rt_hip
 	}
 
 	// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
-	// The quotient t = -num / den is a correctly rounded division (~18 issue slots) and is only worth taking for a lane whose
-	// plane can still be ACCEPTED.  A lane is hopeless — t < min_hit_dist for certain, and no NaN can come of the division —
-	// when num * den is a positive FINITE number (one multiply, one v_cmp_class): then num and den are both finite, non-zero
-	// and of one sign, and -num / den is negative.  Rays that point away from a ground plane — every sky tile's primary
-	// rays, most bounces off the ground — are hopeless wave-wide, and the division is skipped with one ballot.  Anything
-	// else (a zero, an infinity, a NaN, a product that under- or overflows) takes the division as before: the results are the
-	// same bits for every input (tests/test_oracle_kat.py::test_plane_lanes_the_kernels_call_hopeless_...).
+	// The distance t = -num * (1 / den) takes a correctly rounded reciprocal (a handful of issue slots and a guard) and is only
+	// worth taking for a lane whose plane can still be ACCEPTED.  A lane is hopeless — t < min_hit_dist for certain, and no NaN
+	// can come of it — when num * den is a positive FINITE number (one multiply, one v_cmp_class): then num and den are both
+	// finite, non-zero and of one sign, and -num / den is negative.  Rays that point away from a ground plane — every sky tile's
+	// primary rays, most bounces off the ground — are hopeless wave-wide, and the reciprocal is skipped with one vote.  Anything
+	// else (a zero, an infinity, a NaN, a product that under- or overflows) takes it as before: the results are the same bits
+	// for every input (tests/test_oracle_kat.py::test_plane_lanes_the_kernels_call_hopeless_...).
+	// (The two votes are taken from the comparisons themselves and combined on the scalar unit: a vote on their conjunction is
+	// compiled as a select and a second comparison per lane.)
 	__device__ __forceinline__ void test_plane(candidate& best, vec3 o, vec3 d, float4 pl, uint32_t index)
 	{
 		const vec3 n = { pl.x, pl.y, pl.z };
 		const float den = dot(n, d);
 		const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
-		if (__builtin_amdgcn_ballot_w64(crosses) != 0)
+		const unsigned long long crossing = __builtin_amdgcn_ballot_w64(crosses);
+		if (crossing != 0)
 		{
 			const float num = dot(n, o) + pl.w;
 			const bool hopeless = __builtin_amdgcn_classf(num * den, 0x180); // v_cmp_class_f32: bit 7 +subnormal, bit 8 +normal
 			const bool in_reach = crosses && !hopeless;
-			if (__builtin_amdgcn_ballot_w64(in_reach) != 0)
+			if ((crossing & ~__builtin_amdgcn_ballot_w64(hopeless)) != 0)
 			{
 				// (the empty statement keeps hipcc from flattening this wave-uniform branch: everything below is selects,
-				// and it would otherwise run the division on every trip — it did, measured)
-				asm volatile("; the division of a plane test: some lane is in reach" ::: "memory");
-				const float t = divide(-num, in_reach ? den : 1.0f);
+				// and it would otherwise run the reciprocal on every trip — it did, measured)
+				asm volatile("; the reciprocal of a plane test: some lane is in reach" ::: "memory");
+				const float t = (-num) * rcp_rn(in_reach ? den : 1.0f);
 				const bool accept = in_reach && !(t < min_hit_dist) && !(best.have && best.t <= t);
 				best.t = accept ? t : best.t;
 				best.index = accept ? index : best.index;

@@ -42,10 +42,11 @@ namespace rt
 		const vec3& position() const noexcept { return pos_; }
 		const mat3& rotation() const noexcept { return rot_; }
 
+		// reference src/camera.hpp:103-113 (its assertions on NaN / infinity left out)
 		camera& pose(const vec3& pos, const mat3& rot) noexcept
 		{
 			pos_ = pos;
-			rot_ = rot;
+			rot_ = mat3::orthonormalize(rot);
 			return *this;
 		}
 

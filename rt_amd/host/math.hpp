@@ -61,6 +61,27 @@ namespace rt
 					 m[2][0] * v.x + m[2][1] * v.y + m[2][2] * v.z };
 		}
 
+		// muu::orthonormalize(mat3) as rt's camera::pose applies it (reference src/camera.hpp:108): the columns — the images of
+		// +X, +Y, +Z — made orthogonal and of unit length by Gram-Schmidt, in that order.  (muu itself is not readable here:
+		// the ORDER is this mirror's choice.  For a matrix that already is a rotation up to rounding the result differs from the
+		// input in the last bits only; what matters to the plug-in is that the pose is re-normalised at all, as the reference's is —
+		// a rotation accumulated over many mouse moves would otherwise drift.)
+		static mat3 orthonormalize(const mat3& in) noexcept
+		{
+			vec3 x = { in.m[0][0], in.m[1][0], in.m[2][0] }, y = { in.m[0][1], in.m[1][1], in.m[2][1] }, z = { in.m[0][2], in.m[1][2], in.m[2][2] };
+			const auto dot = [](vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; };
+			x = vec3::normalize(x);
+			const float yx = dot(y, x);
+			y = vec3::normalize({ y.x - yx * x.x, y.y - yx * x.y, y.z - yx * x.z });
+			const float zx = dot(z, x), zy = dot(z, y);
+			z = vec3::normalize({ z.x - zx * x.x - zy * y.x, z.y - zx * x.y - zy * y.y, z.z - zx * x.z - zy * y.z });
+			mat3 out;
+			out.m[0][0] = x.x, out.m[1][0] = x.y, out.m[2][0] = x.z;
+			out.m[0][1] = y.x, out.m[1][1] = y.y, out.m[2][1] = y.z;
+			out.m[0][2] = z.x, out.m[1][2] = z.y, out.m[2][2] = z.z;
+			return out;
+		}
+
 		// rotation that takes `forward` (-Z) to `dir` and keeps +Y as "up" as far as possible
 		static mat3 from_3d_direction(vec3 dir) noexcept
 		{

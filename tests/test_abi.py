@@ -57,7 +57,7 @@ def test_kat_library_exports_its_header():
 
 
 def test_abi_version_and_struct_sizes():
-    assert capi.hip_lib().rt_hip_abi_version() == 5
+    assert capi.hip_lib().rt_hip_abi_version() == 6
     # LP64 layout of the PODs in include/rt_hip.h: spheres, planes, materials, sampling, matrix, boxes
     assert C.sizeof(capi.RtHipPartition) == 12
     assert C.sizeof(capi.RtHipScene) == 8 * 6 + 8 * 6 + 8 * 5 + 8 + 64 + 8 * 8

@@ -69,14 +69,17 @@ def test_cpu_baseline_counts_the_cpus_the_container_is_granted(tmp_path, monkeyp
         assert leg["cores"] == 2 and "grants the CPU time of 2" in leg["sample"] and leg["kind"] == "port" and leg["value"] > 0
 
 
-def run_bench(args, launcher=None, timeout=600, expect_rc=0):
+def run_bench(args, launcher=None, timeout=600, expect_rc=0, all_lines=False):
     cmd = (launcher or [sys.executable]) + [str(ROOT / "bench.py")] + args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     out = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
     assert (out.returncode == 0) == (expect_rc == 0), (out.returncode, out.stderr[-2000:])
-    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, out.stdout
-    return json.loads(lines[0])
+    lines = [json.loads(l) for l in out.stdout.splitlines() if l.startswith("{")]
+    # one line — or, under torchrun with several forms, the first form's line as soon as it is done and a final one
+    assert len(lines) == 1 or (len(lines) == 2 and lines[0].get("line", "").startswith("early") and lines[1].get("line") == "final"), out.stdout
+    if all_lines:
+        return lines
+    return lines[-1]
 
 
 @pytest.mark.parametrize("ranks", [1, 3])
@@ -215,6 +218,32 @@ def test_a_form_that_hangs_is_killed_reported_and_fails_the_run():
     assert "hung" in line["paths"]["library"]["status"] and "killed" in line["paths"]["library"]["status"]
     assert line["value_from"] == "shared_frame" and line["paths"]["shared_frame"]["status"] == "ok" and line["paths"]["torch"]["status"] == "ok"
     assert line["value"] == pytest.approx(1920 * 1080 * 16 / (line["ms_per_step"] * 1e-3) / 1e6, rel=1e-3)
+    assert not [name for name in os.listdir("/dev/shm") if name.startswith("rt_hip_bench_")]
+
+
+@pytest.mark.gpu
+def test_the_first_forms_line_is_printed_early_and_the_side_forms_keep_to_the_budget():
+    """the first N > 1 run must fit the driver's time limit whatever the side forms do.  The form `value` comes from
+    runs first and its line is printed (and flushed) as soon as it is done; here the SECOND form hangs, is killed at its own
+    (shorter) deadline, and the third no longer fits the budget and is skipped.  The final line repeats the first form's figures
+    with all three verdicts; the run exits non-zero because a form hung."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    launcher = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port)]
+    os.environ["RT_BENCH_TEST_HANG"] = "shared_frame"
+    try:
+        early, final = run_bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--spp", "16", "--cpu-baseline-seconds", "0", "--library-deadline-s", "40", "--forms-budget-s", "70"],
+                                 launcher=launcher, expect_rc=3, all_lines=True)
+    finally:
+        del os.environ["RT_BENCH_TEST_HANG"]
+    assert early["line"].startswith("early") and early["value_from"] == "library" and early["value"] > 0 and REQUIRED <= set(early)
+    assert set(early["paths"]) == {"library"} and early["paths"]["library"]["status"] == "ok"
+    assert final["line"] == "final" and final["early_line_from"] == "library" and final["value"] == early["value"] and final["ms_per_step"] == early["ms_per_step"]
+    assert "hung" in final["paths"]["shared_frame"]["status"] and "40 s" in final["paths"]["shared_frame"]["status"]
+    assert final["paths"]["torch"]["status"].startswith("skipped: budget")
     assert not [name for name in os.listdir("/dev/shm") if name.startswith("rt_hip_bench_")]
 
 

@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage: tools/gpu_profile_r4.sh TAG "bench.py arguments"      (on the GPU box, inside one gpurun call)
+# usage: tools/gpu_profile_run.sh TAG "bench.py arguments"      (on the GPU box, inside one gpurun call)
 # rocprofv3 over ONE bench.py command: plain run, --kernel-trace --stats, then PMC counters in passes of their own
-# (never together with a trace: MI355X_MICROARCH.md / gpurun's rule).  Summaries land under gpurun_out/r04/TAG/ —
+# (never together with a trace: MI355X_MICROARCH.md / gpurun's rule).  Summaries land under gpurun_out/$ROUND/TAG/ (ROUND defaults to r05) —
 # kernel_stats.csv, render_kernel_durations_ms.txt, pmc_summary.csv, counters.json (stamped with the kernel sources' hash,
 # merged into profiles/pmc_counters.json at home by tools/merge_counters.py).
 set -o pipefail
 TAG=$1; BENCH_ARGS=$2
-OUT=gpurun_out/r04/$TAG; RAW=/tmp/prof_$TAG
+OUT=gpurun_out/${ROUND:-r05}/$TAG; RAW=/tmp/prof_$TAG
 mkdir -p $OUT $RAW
 export TMPDIR=/tmp
 ARGS="bench.py --steps 5 --warmup 2 --cpu-baseline-seconds 0 --no-kernel-only $BENCH_ARGS"

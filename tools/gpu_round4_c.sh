@@ -16,8 +16,8 @@ for a in "--scene basic" "--scene basic_plane" "--scene basic_plane --resident" 
   tail -1 gpurun_out/r04/bench_planes.jsonl | python -c "import json,sys; l=json.loads(sys.stdin.read()); print('$a', l['ms_per_step'], 'ms', l['roofline']['kernel'], l['roofline']['kernel_ms'], 'frac', l['roofline']['frac'])"
 done
 echo "== profiles =="
-bash tools/gpu_profile_r4.sh headline_basic_1080p_256spp "" || exit 1
-bash tools/gpu_profile_r4.sh basic_plane_small "--scene basic_plane" || exit 1
-bash tools/gpu_profile_r4.sh basic_plane_resident "--scene basic_plane --resident" || exit 1
-bash tools/gpu_profile_r4.sh resident_64_spheres "--scene synthetic-64" || exit 1
+bash tools/gpu_profile_run.sh headline_basic_1080p_256spp "" || exit 1
+bash tools/gpu_profile_run.sh basic_plane_small "--scene basic_plane" || exit 1
+bash tools/gpu_profile_run.sh basic_plane_resident "--scene basic_plane --resident" || exit 1
+bash tools/gpu_profile_run.sh resident_64_spheres "--scene synthetic-64" || exit 1
 exit 0

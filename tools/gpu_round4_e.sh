@@ -38,5 +38,5 @@ print(f"{name:12s} plain: wall {plain['ms_per_step']:.4f} kernel(events) {plain[
 PY
 done
 echo "== config 5 counters =="
-bash tools/gpu_profile_r4.sh config5_streamed "--scene synthetic-100k --spp 64 --steps 2 --warmup 1" || exit 1
+bash tools/gpu_profile_run.sh config5_streamed "--scene synthetic-100k --spp 64 --steps 2 --warmup 1" || exit 1
 exit 0

@@ -20,11 +20,11 @@ for a in "" "--locked-frame" "--spp 64" "--scene dielectric" "--width 3840 --hei
   tail -1 gpurun_out/r04/bench_all_configs.jsonl | python -c "import json,sys; l=json.loads(sys.stdin.read()); print('[$a]', l['ms_per_step'], 'ms; kernel', l['roofline']['kernel_ms'], 'frac', l['roofline']['frac'], '; plug-in call', l.get('plug_in_call',{}).get('ms_per_step'), '; other mode', l.get('other_frame_mode',{}).get('ms_per_step'))"
 done
 echo "== profiles =="
-bash tools/gpu_profile_r4.sh headline_basic_1080p_256spp "" || exit 1
-bash tools/gpu_profile_r4.sh basic_plane_small "--scene basic_plane" || exit 1
-bash tools/gpu_profile_r4.sh basic_plane_resident "--scene basic_plane --resident" || exit 1
-bash tools/gpu_profile_r4.sh resident_64_spheres "--scene synthetic-64" || exit 1
-bash tools/gpu_profile_r4.sh basic_tilted_camera "--scene basic --tilt" || exit 1
+bash tools/gpu_profile_run.sh headline_basic_1080p_256spp "" || exit 1
+bash tools/gpu_profile_run.sh basic_plane_small "--scene basic_plane" || exit 1
+bash tools/gpu_profile_run.sh basic_plane_resident "--scene basic_plane --resident" || exit 1
+bash tools/gpu_profile_run.sh resident_64_spheres "--scene synthetic-64" || exit 1
+bash tools/gpu_profile_run.sh basic_tilted_camera "--scene basic --tilt" || exit 1
 echo "== several members on one device: default frame mode against the locked one =="
 for a in "--gpus 4 --same-device" "--gpus 4 --same-device --locked-frame" "--gpus 4 --same-device --direct-frame" "--gpus 4 --same-device --direct-frame --locked-frame"; do
   timeout -k 10 300 python bench.py --steps 10 --warmup 2 --cpu-baseline-seconds 0 $a >> gpurun_out/r04/bench_multi_member.jsonl 2>/tmp/bench.err || { tail -5 /tmp/bench.err; exit 1; }

@@ -16,5 +16,5 @@ import json
 l=json.loads([x for x in open('gpurun_out/r04/bench_torchrun4_gloo.jsonl') if x.startswith('{')][-1])
 print('value_from', l['value_from'], 'ms_per_step', l['ms_per_step']); print({k:(v.get('status'), v.get('ms_per_step')) for k,v in l['paths'].items()})"
 echo "== config 5 counters =="
-bash tools/gpu_profile_r4.sh config5_streamed "--scene synthetic-100k --spp 64 --steps 2 --warmup 1" || exit 1
+bash tools/gpu_profile_run.sh config5_streamed "--scene synthetic-100k --spp 64 --steps 2 --warmup 1" || exit 1
 exit 0

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense the rocprofv3 output of tools/gpu_profile_r4.sh (run on the GPU box) into small committable summaries."""
+"""Condense the rocprofv3 output of tools/gpu_profile_run.sh (run on the GPU box) into small committable summaries."""
 import collections
 import csv
 import json
