@@ -73,6 +73,17 @@ rt_amd/bin/rt_headless: $(HEADLESS_SRC) $(HOST_HDR) $(LIBDIR)/librt_hip.so
 oracle:
 	$(MAKE) -C oracle
 
+# tests/native/soagen_columns.cpp against the reference's own vendored container runtime, compiled from where it lies under
+# /root/reference (nothing is copied; the reference tree exists in the build container only).  The binary goes to oracle/_ref/:
+# git-ignored, not gpurun-ignored — the GPU box runs it with --gpu (tests/test_soagen_columns.py).
+SOAGEN_DIR := /root/reference/vendor
+ifneq ($(wildcard $(SOAGEN_DIR)/soagen.hpp),)
+all: oracle/_ref/soagen_columns
+oracle/_ref/soagen_columns: tests/native/soagen_columns.cpp $(LIBDIR)/librt_hip.so oracle include/rt_hip.h oracle/cpu_ref.h
+	@mkdir -p oracle/_ref
+	$(CXX) -std=c++20 -O1 -Wall -Wextra -I$(SOAGEN_DIR) -Iinclude -Ioracle $< -o $@ -L$(LIBDIR) -lrt_hip -Loracle -loracle -Wl,-rpath,'$$ORIGIN/../../$(LIBDIR)' -Wl,-rpath,'$$ORIGIN/..'
+endif
+
 clean:
 	rm -f $(LIBDIR)/*.so rt_amd/bin/rt_headless
 	$(MAKE) -C oracle clean

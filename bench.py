@@ -136,6 +136,17 @@ def process_cpu_seconds() -> float:
     return usage.ru_utime + usage.ru_stime
 
 
+def cgroup_throttle() -> dict | None:
+    """This process's cgroup CPU-bandwidth record (cgroup v2 cpu.stat): periods in which its threads were stopped because the
+    group had used up its quota, and for how long.  A throttled group's threads ALL stop — the module's carrier helpers with
+    them, whose work the caller's thread then does alone after the kernel."""
+    try:
+        fields = dict(line.split()[:2] for line in (ROOT_CGROUP / "cpu.stat").read_text().splitlines() if line.strip())
+        return {"nr_throttled": int(fields["nr_throttled"]), "throttled_usec": int(fields["throttled_usec"])}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def oracle_frame_digest(scene: str, width: int, height: int, spp: int, max_bounces: int, seed: int, tilt: bool):
     """sha256 of the ORACLE's packed frame for this workload, from tests/golden/frame_digests.json (tools/gen_frame_digests.py:
     made in the build container, minutes of CPU; the oracle does not run here) — None if the workload has no entry."""
@@ -479,6 +490,7 @@ def single_process_main(args) -> None:
         member_kernel_ms = [0.0] * n_gpus
         phase_samples = []
         readback_ms_sum = 0.0
+        throttle0 = cgroup_throttle()
         cpu0 = process_cpu_seconds()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -494,6 +506,7 @@ def single_process_main(args) -> None:
         fence()
         elapsed = time.perf_counter() - t0
         host_cpu_ms_per_step = (process_cpu_seconds() - cpu0) / args.steps * 1e3
+        throttle1 = cgroup_throttle()
         member0 = tracer.member_stats(0) if n_gpus > 1 else stats
         per_rank_kernel_ms = [v / args.steps for v in member_kernel_ms]
         phases = mean_phases(phase_samples)
@@ -502,7 +515,10 @@ def single_process_main(args) -> None:
             {"kernel_ms": round(per_rank_kernel_ms[0], 4), "after_kernel_ms": round(readback_ms_sum / args.steps, 4), "wall_ms": round(elapsed / args.steps * 1e3, 4), "first_call_ms": round(first_call_ms, 3),
              # CPU time the whole process spent per step, ALL threads (getrusage): the caller's thread waiting in the call plus, in
              # the default frame mode, the module's helper threads polling the frame while it is traced
-             "host_cpu_ms_per_step": round(host_cpu_ms_per_step, 4)},
+             "host_cpu_ms_per_step": round(host_cpu_ms_per_step, 4),
+             # periods in which the job's cgroup had run out of CPU quota DURING the timed steps (every thread of the job stops
+             # then, the carrier's helpers included), and for how long: null where the cgroup keeps no such record
+             "cgroup_throttled": {"periods": throttle1["nr_throttled"] - throttle0["nr_throttled"], "ms": round((throttle1["throttled_usec"] - throttle0["throttled_usec"]) * 1e-3, 3)} if throttle0 and throttle1 else None},
             **{k: phases[k] for k in (*PHASE_KEYS, "bands", "bands_early", "bands_early_min", "helpers") if k in phases},
         )
         if n_gpus == 1 and not (args.tiled or args.streamed or args.resident or args.fast):

@@ -212,7 +212,7 @@ enum
 	 * reference src/main.cpp:315-321 want; rt_hip_stats_fetch after such a frame reports render_ms = 0 and segments = 0. */
 	RT_HIP_FLAG_STATS = 1u << 7,
 	/* Work items of the small-scene kernels are whole 16-sample chunks, or — for launches that hold only a few chunks per
-	 * lane of the device — half chunks: the launch code decides by the size of the launch, and the frame is
+	 * lane of the device — half chunks (HISTORY.md §5 "Half-chunk items"): the launch code decides by the size of the launch, and the frame is
 	 * the same bit for bit either way.  These two take the decision away from it (tests; never both). */
 	RT_HIP_FLAG_FORCE_HALF_CHUNKS = 1u << 8,
 	RT_HIP_FLAG_FORCE_WHOLE_CHUNKS = 1u << 9
@@ -372,7 +372,7 @@ RT_HIP_API rt_hip_status rt_hip_scene_upload(rt_hip_ctx* ctx, const rt_hip_scene
  *   d_rgb_f32 optional DEVICE buffer, padded_local_rows x width x 3 floats: the per-pixel mean radiance
  *             before the sqrt "gamma" (mg_ray_tracer.cpp:195), for float-level parity checks.  May be NULL.
  *   seed      key of the counter-based random streams (the reference seeds from std::random_device,
- *             src/random.cpp:12-13, and is not reproducible; see DESIGN.md §3.6).
+ *             src/random.cpp:12-13, and is not reproducible; see DESIGN.md §3.3).
  *   stream    hipStream_t to launch on (NULL = the default stream).  Asynchronous: returns after enqueue.
  */
 RT_HIP_API rt_hip_status rt_hip_render_device(rt_hip_ctx* ctx,

@@ -204,11 +204,11 @@ def sky(dir_y: float) -> np.ndarray:
 
 def primary_ray(scene: RtHipScene, width: int, height: int, x: int, y: int, ka: float = 2.0**23, kb: float = 2.0**23, want_form: bool = False):
     """(origin, direction) of the primary ray of pixel (x, y) whose jitter is (ka, kb) * 2^-24 — the numerators of one
-    generator step; the default is the pixel centre.  want_form: also whether the matrix was taken as a pinhole camera's."""
+    generator step; the default is the pixel centre.  want_form: also which form the matrix was given: 'pinhole', 'eye' or 'general'."""
     o = np.empty(3, dtype=np.float32)
     d = np.empty(3, dtype=np.float32)
     pinhole = lib().oracle_primary_ray(C.byref(scene), width, height, x, y, ka, kb, o.ctypes.data, d.ctypes.data)
-    return (o, d, bool(pinhole)) if want_form else (o, d)
+    return (o, d, {1: "pinhole", 2: "eye", 0: "general"}[pinhole]) if want_form else (o, d)
 
 
 def dielectric_direction(direction, normal, reflectivity: float, u: float):

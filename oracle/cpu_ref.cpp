@@ -37,6 +37,12 @@
 //                            toward_c = fmaf(j1_c, ka, fmaf(j2_c, kb, base_c)), j = d * 2^-24; dir = normalize(toward);
 //                            origin_c = fmaf(kappa, toward_c, eye_c) — the near point, which lies on the line from the
 //                            eye at the fixed fraction kappa = near / (far - near) of the near-to-far vector.
+//                            A PERSPECTIVE matrix that is no pinhole's in binary32 (a tilted camera: rounding noise in its
+//                            w row): all near-to-far lines pass through the eye E = Z.xyz / Z.w (Z = the depth column);
+//                            N' = N.xyz - E N.w, the homogeneous near point relative to it, is affine in the pixel
+//                            position like the pinhole's vector (per-pixel base + jitter share, binary64 constants), and
+//                            so is N.w: toward = s N' (negated if N.w F.w < 0), origin_c = fmaf(toward_c, 1.0f / (s N.w), E_c),
+//                            s = sign(-Z.w).  One division per sample, no far point, no cancellation.
 //                            ANY OTHER matrix: homogeneous near / far points N, F (four fmaf rows each, as
 //                            transform_position); origin = N.xyz * (1.0f / N.w); toward_c = fmaf(F_c, N.w, -(N_c * F.w)),
 //                            negated if N.w * F.w < 0 — far/F.w - near/N.w times the positive factor |N.w F.w|, which
@@ -251,6 +257,14 @@ namespace
 		// the near point as eye + kappa * (near-to-far); constants worked out in binary64
 		bool pinhole_rays;
 		float ray_d0[3], ray_d1[3], ray_d2[3], ray_j1[3], ray_j2[3], ray_eye[3], ray_kappa;
+		// a perspective matrix that is no pinhole's in binary32 (a tilted camera: its w row carries rounding noise): every
+		// near-to-far line still passes through ONE point, the eye E = Z.xyz / Z.w (Z = the matrix's depth column), and the
+		// homogeneous near point relative to it, N' = N.xyz - E N.w, is affine in the pixel position: the near-to-far
+		// vector is N' (times a sign), the near point E + N' / N.w.  Constants in binary64, as above.
+		bool eye_rays;
+		float eye_q0[3], eye_q1[3], eye_q2[3], eye_jq1[3], eye_jq2[3]; // s N' = q0 + q1 x + q2 y; its share per jitter numerator
+		float eye_w0, eye_w1, eye_w2, eye_jw1, eye_jw2;				  // s N.w likewise                       (s = sign(-Z.w))
+		float eye_e[3], eye_zws;										  // E;  s Z.w
 		// any other matrix: rows of the homogeneous near / far points
 		float mx[4], my[4], k_near[4], k_far[4];
 		frame_keys keys;
@@ -287,6 +301,33 @@ namespace
 			}
 			const float* k_near = f.k_near;
 			const float* k_far = f.k_far;
+			f.eye_rays = false;
+			{
+				// N_r(px, py) = mx_r X + my_r Y + k_near_r with X = (2/W) px - 1, Y = -(2/H) py + 1  =  n0_r + n1_r px + n2_r py
+				const double sx = 2.0 / static_cast<double>(w), sy = -(2.0 / static_cast<double>(h));
+				const double zw = M[3 * 4 + 2];
+				const double e[3] = { M[0 * 4 + 2] / zw, M[1 * 4 + 2] / zw, M[2 * 4 + 2] / zw };
+				const double sign = zw < 0.0 ? 1.0 : -1.0; // sign(-Z.w): s N' points from near to far where N.w F.w > 0
+				const double n1w = static_cast<double>(M[12]) * sx, n2w = static_cast<double>(M[13]) * sy;
+				const double n0w = static_cast<double>(k_near[3]) - static_cast<double>(M[12]) + static_cast<double>(M[13]);
+				bool finite = zw != 0.0 && std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && std::isfinite(n0w) && std::isfinite(n1w) && std::isfinite(n2w);
+				for (int c = 0; c < 3 && finite; c++)
+				{
+					const double mx = M[c * 4 + 0], my = M[c * 4 + 1];
+					const double n1 = mx * sx, n2 = my * sy, n0 = static_cast<double>(k_near[c]) - mx + my;
+					f.eye_q0[c] = static_cast<float>(sign * (n0 - e[c] * n0w)), f.eye_q1[c] = static_cast<float>(sign * (n1 - e[c] * n1w)), f.eye_q2[c] = static_cast<float>(sign * (n2 - e[c] * n2w));
+					f.eye_jq1[c] = f.eye_q1[c] * 0x1.0p-24f, f.eye_jq2[c] = f.eye_q2[c] * 0x1.0p-24f;
+					f.eye_e[c] = static_cast<float>(e[c]);
+					finite = std::isfinite(f.eye_q0[c]) && std::isfinite(f.eye_q1[c]) && std::isfinite(f.eye_q2[c]);
+				}
+				if (finite)
+				{
+					f.eye_w0 = static_cast<float>(sign * n0w), f.eye_w1 = static_cast<float>(sign * n1w), f.eye_w2 = static_cast<float>(sign * n2w);
+					f.eye_jw1 = f.eye_w1 * 0x1.0p-24f, f.eye_jw2 = f.eye_w2 * 0x1.0p-24f;
+					f.eye_zws = static_cast<float>(sign * zw);
+					f.eye_rays = true;
+				}
+			}
 			f.pinhole_rays = false;
 			if (M[12] == 0.0f && M[13] == 0.0f && k_near[3] != 0.0f && k_far[3] != 0.0f && std::isfinite(k_near[3]) && std::isfinite(k_far[3]))
 			{
@@ -374,7 +415,26 @@ namespace
 			}
 			return { origin, normalize(toward) }; // :190-193
 		}
-		// any other matrix: screen_to_world (camera.hpp:42-48) for depth 0 and 1 in homogeneous form; ONE division
+		if (f.eye_rays) // a perspective matrix: the near point relative to the eye, and the eye plus that over N.w
+		{
+			float t[3];
+			for (int c = 0; c < 3; c++)
+			{
+				const float base = std::fmaf(f.eye_q1[c], fx, std::fmaf(f.eye_q2[c], fy, f.eye_q0[c])); // once per pixel
+				t[c] = std::fmaf(f.eye_jq1[c], ka, std::fmaf(f.eye_jq2[c], kb, base));
+			}
+			const float w_base = std::fmaf(f.eye_w1, fx, std::fmaf(f.eye_w2, fy, f.eye_w0)); // once per pixel
+			const float ws = std::fmaf(f.eye_jw1, ka, std::fmaf(f.eye_jw2, kb, w_base));		 // s N.w
+			const float inv = 1.0f / ws;
+			const vec3 near_pos = { std::fmaf(t[0], inv, f.eye_e[0]), std::fmaf(t[1], inv, f.eye_e[1]), std::fmaf(t[2], inv, f.eye_e[2]) }; // :190
+			// far - near (:191,193) = N' (-Z.w) / (N.w F.w) = (s N') |Z.w| / (N.w F.w): s N', with the sign of N.w F.w = (s N.w)(s N.w + s Z.w)
+			vec3 toward = { t[0], t[1], t[2] };
+			if (ws * (ws + f.eye_zws) < 0.0f)
+				toward = { -toward.x, -toward.y, -toward.z };
+			return { near_pos, normalize(toward) };
+		}
+		// any other matrix (no finite eye: an orthographic frustum): screen_to_world (camera.hpp:42-48) for depth 0 and 1 in
+		// homogeneous form; ONE division
 		const float px = std::fmaf(ka, 0x1.0p-24f, fx), py = std::fmaf(kb, 0x1.0p-24f, fy); // == fx + ka * 2^-24: the product is exact
 		const float ndc_x = std::fmaf(px, f.sx, -1.0f), ndc_y = std::fmaf(py, -f.sy, 1.0f);
 		float N[4], F[4];
@@ -963,7 +1023,7 @@ extern "C" int oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uin
 	out_dir[0] = r.dir.x;
 	out_dir[1] = r.dir.y;
 	out_dir[2] = r.dir.z;
-	return f.pinhole_rays ? 1 : 0;
+	return f.pinhole_rays ? 1 : (f.eye_rays ? 2 : 0);
 }
 
 extern "C" void oracle_dielectric_direction(const float* dir, const float* normal, float reflectivity, float u, float* out_dir, float* out_reflect_prob)

@@ -90,7 +90,8 @@ void oracle_dielectric_direction(const float* dir, const float* normal, float re
 /* ray vs axis-aligned box (center, half extents): 1 = hit and *out_t set.  The slab test of the preview. */
 int oracle_hits_box(const float* origin, const float* dir, const float* center, const float* extents, float* out_t);
 /* primary ray of pixel (x, y) for the jitter (ka, kb) * 2^-24 (numerators of one generator step; 2^23 = the centre);
- * returns 1 if the matrix was taken as a pinhole camera's, 0 if it went through the general (one-division) form */
+ * returns 1 if the matrix was taken as a pinhole camera's, 2 as a perspective matrix with a finite eye (the eye form),
+ * 0 if it went through the general homogeneous form */
 int oracle_primary_ray(const rt_hip_scene* scene, uint32_t width, uint32_t height, uint32_t x, uint32_t y, float ka, float kb, float* out_origin, float* out_dir);
 
 #ifdef __cplusplus

@@ -328,7 +328,7 @@ extern "C" rt_hip_status rt_hip_kat_exhaustive_math(rt_hip_ctx* ctx, uint64_t ou
 
 #ifdef RT_HIP_REGION_COUNTERS
 // experiment variant only: out[0..12] = runs, out[13..25] = lanes of the most recent launch on this context
-extern "C" rt_hip_status rt_hip_debug_region_counters(rt_hip_ctx* ctx, uint64_t* out)
+extern "C" __attribute__((visibility("default"))) rt_hip_status rt_hip_debug_region_counters(rt_hip_ctx* ctx, uint64_t* out)
 {
 	if (!ctx || !out)
 		return kat_fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_debug_region_counters: NULL argument");
@@ -346,7 +346,7 @@ extern "C" rt_hip_status rt_hip_debug_region_counters(rt_hip_ctx* ctx, uint64_t*
 #ifdef RT_HIP_WAVE_CLOCKS
 // experiment variant only: out[3 * w + {0, 1, 2}] = start / queue-dry / end tick (100 MHz) of wave w of the most recent
 // persistent launch on this context, for w < *count (in: capacity of `out` in waves; out: waves the build records)
-extern "C" rt_hip_status rt_hip_debug_wave_clocks(rt_hip_ctx* ctx, uint64_t* out, uint32_t* count)
+extern "C" __attribute__((visibility("default"))) rt_hip_status rt_hip_debug_wave_clocks(rt_hip_ctx* ctx, uint64_t* out, uint32_t* count)
 {
 	if (!ctx || !out || !count)
 		return kat_fail(RT_HIP_INVALID_ARGUMENT, "rt_hip_debug_wave_clocks: NULL argument");

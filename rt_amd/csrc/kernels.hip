@@ -53,17 +53,13 @@
 
 // waves per SIMD the kernel variants are compiled for (register budget = 512 / waves): measured, see render_queue
 #ifndef RT_HIP_WAVES_FEW
-#define RT_HIP_WAVES_FEW 7 // small kernel with 1..4 spheres
+#define RT_HIP_WAVES_FEW 7 // scalar-register kernels in general
 #endif
+// ... and those that hold six or more spheres and seven or more primitives (7 + 0, 8 + 0, 6 + 1, 7 + 1, 6 + 2): 80 registers instead of
+// 72 spare them most of their scratch, which costs more than the seventh wave brings — every (spheres, planes) build at 7 and at 6 waves:
+// profiles/r05/small_sweep.txt (round 4 had settled the same question build by build: waves_full_ab.txt)
 #ifndef RT_HIP_WAVES_MANY
-#define RT_HIP_WAVES_MANY 7 // small kernel with 5..8 spheres
-#endif
-// small kernel with seven spheres and a plane (dielectric.toml with the plane it carries one comment away): the plane test's
-// division on top of seven spheres spills at 72 registers in the loop's hottest stretch — 3.99 ms at 7 waves per SIMD, 3.59 at 6.
-// Nothing else wants 6: eight spheres and seven primitives of any kind prefer 7 by 2.5-3 %, 6 + 2 by 1 %, 5 + 3 does not care
-// (profiles/r04/waves_full_ab.txt)
-#ifndef RT_HIP_WAVES_SEVEN_AND_PLANE
-#define RT_HIP_WAVES_SEVEN_AND_PLANE 6
+#define RT_HIP_WAVES_MANY 6
 #endif
 #ifndef RT_HIP_WAVES_RESIDENT
 #define RT_HIP_WAVES_RESIDENT 7
@@ -216,8 +212,8 @@ namespace rt_hip
 			vec3 throughput;	// product of attenuations so far (trace unrolled front to back)
 			vec3 chunk_sum;		// running sum of the chunk of samples in flight (:186,193)
 			// what a pixel's samples start from (frame_params): pinhole camera — the near-to-far vector through the pixel's
-			// corner; any other matrix — (x, y, -) of the pixel
-			float base[3];
+			// corner; eye form — s N' and s N.w of the corner; homogeneous form — (x, y, -, -) of the pixel
+			float base_x, base_y, base_z, base_w; // (named words, not an array: hipcc otherwise keeps half of it in scratch)
 			stream_keys keys;	// random streams of the pixel (contract.hpp): the key of its hash function and its counter stride
 			uint32_t counter;	// random stream position
 			// The samples of an item, counted in STREAM POSITIONS: a sample's window starts at stride * (index << 12)
@@ -444,7 +440,7 @@ namespace rt_hip
 		// LDS-resident kernel (+35 % on basic.toml); now they keep the scalar-register kernel, in a build of it that carries
 		// the 18 scalars of the general form INSTEAD of the 18 of the affine one (both would not fit its scalar registers).
 		template <int NS, bool SM, bool HALF = false, int NP = 0, bool GC = false>
-		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS == 7 && NP == 1 ? RT_HIP_WAVES_SEVEN_AND_PLANE : (NS >= 5 ? RT_HIP_WAVES_MANY : (NS == 0 ? RT_HIP_WAVES_RESIDENT : RT_HIP_WAVES_FEW)))) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS == 0 ? RT_HIP_WAVES_RESIDENT : (NS >= 6 && NS + NP >= 7 ? RT_HIP_WAVES_MANY : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
@@ -459,7 +455,8 @@ namespace rt_hip
 			// [NS > 0] 8 geometry (with the scatter function) + 8 shading float4s | [NS == 0] all primitives; then the chunk slots
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
-			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (NS == 0 ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
+			constexpr bool RESIDENT = NS == 0; // all primitives in LDS
+			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (RESIDENT ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -477,7 +474,7 @@ namespace rt_hip
 					}
 				}
 			}
-			else if (NS == 0)
+			else if (RESIDENT)
 			{
 				for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
 					lds[i] = s.primitive_geometry[i];
@@ -488,7 +485,11 @@ namespace rt_hip
 			uint32_t region_runs[device_counters::regions] = {}, region_lanes[device_counters::regions] = {};
 #endif
 			constexpr bool ROLLING = NS < 0;
-			constexpr bool PINHOLE_ONLY = NS > 0 && !GC, GENERAL_ONLY = NS > 0 && GC; // the camera form a scalar-register kernel is built for
+			// the camera form a scalar-register kernel is built for: the pinhole form, or (GC) the eye form.  A matrix without a
+			// finite eye (an orthographic frustum: nothing rt's camera can produce) takes the LDS-resident kernel, which carries all
+			// three forms — together with seven spheres their scalars do not fit the scalar registers, and hipcc then reloads the
+			// SPHERES from the argument block inside the loop (round 5: dielectric.toml through a tilted camera 3.85 ms).
+			constexpr bool PINHOLE_ONLY = NS > 0 && !GC, EYE_ONLY = NS > 0 && GC;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
 			const uint32_t chunk_items = q.chunks << q.pixels_log2;	   // chunks of one pixel tile: P x K
@@ -850,7 +851,7 @@ namespace rt_hip
 					{
 						// The discriminants of a GROUP of spheres first (independent straight-line code with scalar operands), one
 						// branch for "no lane can hit any of them", then their square-root halves in index order.  Up to four spheres
-						// are one group.  From five spheres on they go in groups of four: every discriminant of a group is three live
+						// are one group.  From five spheres on they go in groups of three: every discriminant of a group is three live
 						// vector registers until its square-root half has run, and seven or eight at once put the kernel over its
 						// budget (72 at 7 waves per SIMD) — round 4 lived with 12-16 bytes of scratch there; in round 5 the same source
 						// took 84-124 bytes with the contract-v4 tail, and dielectric.toml went from 2.7 to 9.4 ms
@@ -860,7 +861,7 @@ namespace rt_hip
 #ifdef RT_HIP_PROBE_GROUP
 						constexpr int group = RT_HIP_PROBE_GROUP; // (A/B builds)
 #else
-						constexpr int group = spheres_ns <= 4 ? spheres_ns : 4;
+						constexpr int group = spheres_ns <= 4 ? spheres_ns : 3;
 #endif
 #pragma unroll
 						for (int first = 0; first < NS; first += group)
@@ -897,7 +898,7 @@ namespace rt_hip
 								test_plane(best_plane, st.origin, st.dir, small.geometry[(NS > 0 ? NS : 0) + j], static_cast<uint32_t>(j));
 							uint32_t index;
 							kind = select_hit(best, best_plane, distance, index);
-							small_index = kind == 2u ? static_cast<uint32_t>(NS) + index : index; // the winner's slot
+							small_index = kind == 1u ? best.index : static_cast<uint32_t>(NS) + best_plane.index; // the winner's slot (one select; with one plane its index is a constant)
 						}
 						else
 						{
@@ -912,7 +913,7 @@ namespace rt_hip
 						candidate planes = { 0.0f, 0u, false };
 						candidate spheres = { 0.0f, 0u, false };
 						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
-						const float4* const primitives = NS == 0 ? lds : geometry;
+						const float4* const primitives = RESIDENT ? lds : geometry;
 						scan_lds<false>(planes, st.origin, st.dir, primitives + s.n_spheres, s.n_planes, 0);
 						if (NS == -2)
 						{
@@ -921,6 +922,14 @@ namespace rt_hip
 							else
 								scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
 						}
+						// From a few dozen spheres on the resident kernel reads the sphere table as the streamed kernel does — wave-uniform
+						// scalar loads of (c, r^2) groups from the table in memory, the next group's load issued before this group's
+						// probes — instead of broadcast reads from its LDS copy: a table of this size sits in the scalar cache, the probes
+						// take their operands from scalar registers, and neither the LDS pipe nor four vector registers per sphere in
+						// flight are spent on it (64 spheres x 256 spp 12.9 -> 12.5 ms, 200 spheres 9.6 -> 8.7, 700 33.3 -> 29.9; below
+						// about 40 the LDS copy is ahead: 12 spheres 1.17 against 1.24 ms; profiles/r05/resident_scalar_ab.txt)
+						else if (NS == 0 && s.n_spheres >= resident_scalar_scan_from)
+							scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
 						else
 							scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
 						uint32_t index;
@@ -975,14 +984,25 @@ namespace rt_hip
 					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
 					{
 						const float fx = static_cast<float>(lx), fy = static_cast<float>(gy);
-						if (PINHOLE_ONLY || (!GENERAL_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
+						if (PINHOLE_ONLY || (!EYE_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
 						{
-#pragma unroll
-							for (int c = 0; c < 3; c++)
-								st.base[c] = fma(p.ray_d1[c], fx, fma(p.ray_d2[c], fy, p.ray_d0[c]));
+							st.base_x = fma(p.ray_d1[0], fx, fma(p.ray_d2[0], fy, p.ray_d0[0]));
+							st.base_y = fma(p.ray_d1[1], fx, fma(p.ray_d2[1], fy, p.ray_d0[1]));
+							st.base_z = fma(p.ray_d1[2], fx, fma(p.ray_d2[2], fy, p.ray_d0[2]));
+							st.base_w = 0.0f;
+						}
+						else if (EYE_ONLY || p.eye_form) // (wave-uniform)
+						{
+							st.base_x = fma(p.eye_q1[0], fx, fma(p.eye_q2[0], fy, p.eye_q0[0]));
+							st.base_y = fma(p.eye_q1[1], fx, fma(p.eye_q2[1], fy, p.eye_q0[1]));
+							st.base_z = fma(p.eye_q1[2], fx, fma(p.eye_q2[2], fy, p.eye_q0[2]));
+							st.base_w = fma(p.eye_w1, fx, fma(p.eye_w2, fy, p.eye_w0));
 						}
 						else
-							st.base[0] = fx, st.base[1] = fy, st.base[2] = 0.0f;
+						{
+							st.base_x = fx, st.base_y = fy;
+							st.base_z = st.base_w = 0.0f;
+						}
 					}
 					st.keys.function_key = pixel_function_key(p.frame_key_a, gy * p.width + lx); // image_view::position_of, image.hpp:155-159
 					st.keys.stride = pixel_stride(p.frame_key_b, st.keys.function_key);
@@ -1216,23 +1236,42 @@ namespace rt_hip
 								counter = counter_at_start;
 							}
 						}
-						if (PINHOLE_ONLY || (!GENERAL_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
+						if (PINHOLE_ONLY || (!EYE_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
 						{
 							// rt's camera: the near-to-far vector from the pixel's base and the jitter, the near point from it (contract
 							// v4; constants from the host).  The LDS / big-scene kernels carry both forms; a scalar-register kernel is
 							// built for ONE of them (GC): as kernel arguments the two sets of scalars together would cost its loop, which
 							// lives on its scalar registers, a spill per lane mask.
-							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base[0])), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base[1])),
-									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base[2])) };
+							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base_x)), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base_y)),
+									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base_z)) };
 							st.origin = { fma(p.ray_kappa, toward.x, p.ray_eye[0]), fma(p.ray_kappa, toward.y, p.ray_eye[1]), fma(p.ray_kappa, toward.z, p.ray_eye[2]) };
+						}
+						else if (EYE_ONLY || p.eye_form) // (wave-uniform)
+						{
+							// a perspective matrix that is no pinhole's in binary32 — a camera that is not axis-aligned: rounding noise in
+							// its w row.  Every near-to-far line passes through the eye E; the near point relative to it (times N.w) and
+							// N.w itself move with the jitter like the pinhole's vector does: ONE reciprocal per sample, no far point
+							// (round 4: two reciprocals and sixteen multiply-adds for the two points).
+							toward = { fma(p.eye_jq1[0], jx, fma(p.eye_jq2[0], jy, st.base_x)), fma(p.eye_jq1[1], jx, fma(p.eye_jq2[1], jy, st.base_y)),
+									   fma(p.eye_jq1[2], jx, fma(p.eye_jq2[2], jy, st.base_z)) };
+							const float ws = fma(p.eye_jw1, jx, fma(p.eye_jw2, jy, st.base_w));
+							const float inv = rcp_rn(ws);
+							st.origin = { fma(toward.x, inv, p.eye_e[0]), fma(toward.y, inv, p.eye_e[1]), fma(toward.z, inv, p.eye_e[2]) };
+							// far - near = s N' |Z.w| / (N.w F.w): s N' unless the near and far points lie on different sides of w = 0
+							if (__builtin_amdgcn_ballot_w64(ws * (ws + p.eye_zws) < 0.0f) != 0)
+							{
+								asm volatile("; restart: some lane's near and far points straddle w = 0" ::: "memory");
+								if (ws * (ws + p.eye_zws) < 0.0f)
+									toward = { -toward.x, -toward.y, -toward.z };
+							}
 						}
 						else
 						{
-							// any other matrix: un-project to depth 0 and depth 1 (camera.hpp:42-48) in homogeneous form, N and F.  The
+							// no finite eye (an orthographic frustum): un-project to depth 0 and depth 1 (camera.hpp:42-48) in homogeneous form, N and F.  The
 							// near point needs its division; the direction does not — far / F.w - near / N.w is F N.w - N F.w over
 							// N.w F.w, and normalize() removes a positive factor: one reciprocal per sample (round 4: two).
-							const float px = fma(jx, random_scale, st.base[0]); // == x + jx * 2^-24: the product is exact
-							const float py = fma(jy, random_scale, st.base[1]);
+							const float px = fma(jx, random_scale, st.base_x); // == x + jx * 2^-24: the product is exact
+							const float py = fma(jy, random_scale, st.base_y);
 							const float ndc_x = fma(px, p.sx, -1.0f);
 							const float ndc_y = fma(py, p.neg_sy, 1.0f);
 							float N[4], F[4];
@@ -1526,7 +1565,7 @@ namespace rt_hip
 	}
 
 #ifndef RT_HIP_FAST_BUILD
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
 		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
@@ -1535,7 +1574,8 @@ namespace rt_hip
 			return RT_HIP_KERNEL_TILED;
 		// up to 8 primitives: at least one sphere, at most three planes (round 4: neither a plane nor a camera whose w varies
 		// over the frame pushes a scene off this kernel any more)
-		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
+		// ... through a camera with an eye (`perspective`: the pinhole or the eye form; the scalar-register kernels are built for those)
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && perspective && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
 		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against
@@ -1717,7 +1757,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.pinhole != 0 || frame.eye_form != 0);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes,

@@ -82,6 +82,21 @@ namespace rt_hip
 		float ray_j1[3], ray_j2[3];
 		float ray_eye[3];
 		float ray_kappa;
+		// eye_form != 0: the matrix is a PERSPECTIVE one (its depth column Z has a finite point E = Z.xyz / Z.w: the eye every
+		// near-to-far line passes through) — what the general-camera kernels use for a camera that is not axis-aligned.  With
+		// N = the homogeneous near point, N' = N.xyz - E N.w and s = sign(-Z.w), both s N' and s N.w are affine in the pixel
+		// position (binary64 constants, like the pinhole's):
+		//   base_c = fma(eye_q1[c], x, fma(eye_q2[c], y, eye_q0[c])),   base_w = fma(eye_w1, x, fma(eye_w2, y, eye_w0))    per pixel
+		//   t_c    = fma(eye_jq1[c], ka, fma(eye_jq2[c], kb, base_c)),  ws     = fma(eye_jw1, ka, fma(eye_jw2, kb, base_w)) per sample
+		//   origin_c = fma(t_c, 1 / ws, eye_e[c]);   toward = t, negated if ws * (ws + eye_zws) < 0   (= N.w F.w < 0)
+		// One division per sample and no far point.  A matrix without a finite eye (an orthographic frustum) takes the
+		// homogeneous form from mx .. k_far above.
+		uint32_t eye_form;
+		float eye_q0[3], eye_q1[3], eye_q2[3];
+		float eye_jq1[3], eye_jq2[3];
+		float eye_w0, eye_w1, eye_w2, eye_jw1, eye_jw2;
+		float eye_e[3];
+		float eye_zws;
 	};
 
 	// the whole scene of the `small` kernel, passed by value as a kernel argument (-> SGPRs); host copy kept by the context
@@ -170,6 +185,10 @@ namespace rt_hip
 #endif
 	};
 
+#ifndef RT_HIP_RESIDENT_SCALAR_FROM
+#define RT_HIP_RESIDENT_SCALAR_FROM 40
+#endif
+	constexpr uint32_t resident_scalar_scan_from = RT_HIP_RESIDENT_SCALAR_FROM; // spheres from which the resident kernel scans through the scalar cache (kernels.hip)
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
 	constexpr uint32_t streamed_from_primitives = 704; // ... which the launch code prefers up to this many
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
@@ -192,7 +211,7 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective /* the frame's camera has an eye: frame_params::pinhole or eye_form */);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,

@@ -109,6 +109,34 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	// out in binary64, in THIS order of operations, and rounded to binary32 once.  A matrix is taken as a pinhole's when the
 	// near point's motion per pixel is kappa times the near-to-far vector's to within 1e-5 (relative; 1e-10 of a pixel
 	// step: far below what binary32 resolves); anything else goes through the homogeneous form.
+	f.eye_form = 0u;
+	{
+		// the eye form (oracle/cpu_ref.cpp make_frame has the same lines): N_r(px, py) = mx_r X + my_r Y + k_near_r with
+		// X = (2/W) px - 1, Y = -(2/H) py + 1, i.e. n0_r + n1_r px + n2_r py; E = Z.xyz / Z.w; s = sign(-Z.w)
+		const double sx = 2.0 / static_cast<double>(width), sy = -(2.0 / static_cast<double>(height));
+		const double zw = M[3 * 4 + 2];
+		const double e[3] = { M[0 * 4 + 2] / zw, M[1 * 4 + 2] / zw, M[2 * 4 + 2] / zw };
+		const double sign = zw < 0.0 ? 1.0 : -1.0;
+		const double n1w = static_cast<double>(M[12]) * sx, n2w = static_cast<double>(M[13]) * sy;
+		const double n0w = static_cast<double>(f.k_near[3]) - static_cast<double>(M[12]) + static_cast<double>(M[13]);
+		bool finite = zw != 0.0 && std::isfinite(e[0]) && std::isfinite(e[1]) && std::isfinite(e[2]) && std::isfinite(n0w) && std::isfinite(n1w) && std::isfinite(n2w);
+		for (int c = 0; c < 3 && finite; c++)
+		{
+			const double mx = M[c * 4 + 0], my = M[c * 4 + 1];
+			const double n1 = mx * sx, n2 = my * sy, n0 = static_cast<double>(f.k_near[c]) - mx + my;
+			f.eye_q0[c] = static_cast<float>(sign * (n0 - e[c] * n0w)), f.eye_q1[c] = static_cast<float>(sign * (n1 - e[c] * n1w)), f.eye_q2[c] = static_cast<float>(sign * (n2 - e[c] * n2w));
+			f.eye_jq1[c] = f.eye_q1[c] * 0x1.0p-24f, f.eye_jq2[c] = f.eye_q2[c] * 0x1.0p-24f;
+			f.eye_e[c] = static_cast<float>(e[c]);
+			finite = std::isfinite(f.eye_q0[c]) && std::isfinite(f.eye_q1[c]) && std::isfinite(f.eye_q2[c]);
+		}
+		if (finite)
+		{
+			f.eye_w0 = static_cast<float>(sign * n0w), f.eye_w1 = static_cast<float>(sign * n1w), f.eye_w2 = static_cast<float>(sign * n2w);
+			f.eye_jw1 = f.eye_w1 * 0x1.0p-24f, f.eye_jw2 = f.eye_w2 * 0x1.0p-24f;
+			f.eye_zws = static_cast<float>(sign * zw);
+			f.eye_form = 1u;
+		}
+	}
 	f.pinhole = 0u;
 	if (f.mx[3] == 0.0f && f.my[3] == 0.0f && f.k_near[3] != 0.0f && f.k_far[3] != 0.0f && std::isfinite(f.k_near[3]) && std::isfinite(f.k_far[3]))
 	{
@@ -148,7 +176,7 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	rolling_buffers rolling;
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel);
+		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.pinhole != 0 || f.eye_form != 0);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
 		queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes, variant == RT_HIP_KERNEL_STREAMED && ctx->scene.n_spheres >= sparse_launch_min_spheres);

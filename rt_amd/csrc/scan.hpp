@@ -79,9 +79,12 @@ namespace rt_hip
 		if (crossing != 0)
 		{
 			const float num = dot(n, o) + pl.w;
-			const bool hopeless = __builtin_amdgcn_classf(num * den, 0x180); // v_cmp_class_f32: bit 7 +subnormal, bit 8 +normal
-			const bool in_reach = crosses && !hopeless;
-			if ((crossing & ~__builtin_amdgcn_ballot_w64(hopeless)) != 0)
+			// (two comparisons whose votes the scalar unit combines, not one v_cmp_class: hipcc turns a vote on a class test into
+			// a select and a second comparison per lane.  "positive, finite, not zero" either way; a NaN fails both.)
+			const float product = num * den;
+			const bool positive = product > 0.0f, finite = product < __builtin_inff();
+			const bool in_reach = crosses && !(positive && finite);
+			if ((crossing & ~(__builtin_amdgcn_ballot_w64(positive) & __builtin_amdgcn_ballot_w64(finite))) != 0)
 			{
 				// (the empty statement keeps hipcc from flattening this wave-uniform branch: everything below is selects,
 				// and it would otherwise run the reciprocal on every trip — it did, measured)

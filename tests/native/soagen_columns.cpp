@@ -13,6 +13,11 @@
 // once as they are and once with everything behind size() POISONED (NaN floats, 0xFFFFFFFF indices).  "Never read past
 // size()" then means: same verdict, same fingerprint, same frame — and the same as from plain packed std::vectors.
 //
+// `--gpu` (round 5, VERDICT r4 #3 iv): additionally the product's drop-in call, rt_hip_render on device 0, is handed the very
+// same soagen-backed pointers — clean and with the padding poisoned — and its frame must be the oracle's.  The GPU box has no
+// reference tree: the Makefile builds this program here into oracle/_ref/ (git-ignored, travels with gpurun like the
+// product's own .so files) and tests/test_soagen_columns.py's gpu case runs that binary.
+//
 // build (tests/test_soagen_columns.py does it): g++ -std=c++20 -O1 -I/root/reference/vendor -Iinclude -Ioracle
 //            tests/native/soagen_columns.cpp -o <out> -Lrt_amd/lib -lrt_hip -Loracle -loracle -Wl,-rpath,<both>
 #include <soagen.hpp>
@@ -107,10 +112,42 @@ namespace
 			for (int c = 0; c < 4; c++)
 				s.inverse_view_projection[r * 4 + c] += eye[r] * s.inverse_view_projection[3 * 4 + c];
 	}
+
+	// --gpu: the same columns through the product's drop-in call on device 0 — rt_hip_render reads them (fingerprint, upload)
+	// and the frame must be the oracle's, bit for bit, packed pixels and float mean
+	bool on_gpu = false;
+	rt_hip_ctx* gpu = nullptr;
+	void render_on_gpu(const rt_hip_scene& s, uint32_t w, uint32_t h, const frame& want, const char* what)
+	{
+		if (!on_gpu)
+			return;
+		if (!gpu && rt_hip_create(&gpu, 0) != RT_HIP_OK)
+		{
+			std::printf("FAILED rt_hip_create: %s\n", rt_hip_last_error());
+			failures++;
+			on_gpu = false;
+			return;
+		}
+		std::vector<uint32_t> rgba(static_cast<size_t>(w) * h, 0);
+		std::vector<float> rgb(static_cast<size_t>(w) * h * 3, 0.0f);
+		rt_hip_stats stats{};
+		const rt_hip_status st = rt_hip_render(gpu, &s, rgba.data(), w, h, 5, 0, rgb.data(), &stats);
+		if (st != RT_HIP_OK)
+		{
+			std::printf("FAILED rt_hip_render (%s): %s\n", what, rt_hip_last_error());
+			failures++;
+			return;
+		}
+		EXPECT(rgba == want.rgba);
+		EXPECT(std::memcmp(rgb.data(), want.rgb.data(), rgb.size() * sizeof(float)) == 0);
+		EXPECT(stats.segments == want.stats.segments);
+		std::printf("gpu (%s): kernel variant %u, %llu segments, frame %s the oracle's\n", what, stats.kernel_variant, static_cast<unsigned long long>(stats.segments), rgba == want.rgba ? "equals" : "DIFFERS FROM");
+	}
 }
 
-int main()
+int main(int argc, char** argv)
 {
+	on_gpu = argc > 1 && std::strcmp(argv[1], "--gpu") == 0;
 	materials_table materials;
 	planes_table planes;
 	spheres_table spheres;
@@ -162,6 +199,7 @@ int main()
 	uint64_t print_clean = 0;
 	EXPECT(rt_hip_scene_check(&s, &print_clean) == RT_HIP_OK);
 	const frame clean = render(s, width, height);
+	render_on_gpu(s, width, height, clean, "soagen columns");
 	EXPECT(clean.stats.segments > static_cast<uint64_t>(width) * height * 3); // something was hit: paths continue
 	EXPECT(clean.stats.sphere_tests == clean.stats.segments * static_cast<uint64_t>(n_spheres));
 
@@ -188,6 +226,7 @@ int main()
 	EXPECT(rt_hip_scene_check(&s, &print_poisoned) == RT_HIP_OK); // an index read behind size() would be "out-of-range"
 	EXPECT(print_poisoned == print_clean);						   // a byte read behind size() would move the fingerprint
 	const frame poisoned = render(s, width, height);
+	render_on_gpu(s, width, height, clean, "soagen columns, padding poisoned"); // (other bytes behind size(): the fingerprint must not move, nothing re-uploaded)
 	EXPECT(poisoned.rgba == clean.rgba);
 	EXPECT(std::memcmp(poisoned.rgb.data(), clean.rgb.data(), clean.rgb.size() * sizeof(float)) == 0);
 	EXPECT(poisoned.stats.segments == clean.stats.segments);
@@ -223,6 +262,8 @@ int main()
 	uint64_t print_edited = 0;
 	EXPECT(rt_hip_scene_check(&s, &print_edited) == RT_HIP_OK && print_edited != print_clean);
 
+	if (gpu)
+		rt_hip_destroy(gpu);
 	std::printf("%s: %zu spheres in capacity %zu, %zu planes in capacity %zu, %zu materials in capacity %zu; %llu segments; fingerprint %016llx\n", failures ? "FAILED" : "OK",
 				spheres.size(), spheres.capacity(), planes.size(), planes.capacity(), materials.size(), materials.capacity(), static_cast<unsigned long long>(clean.stats.segments),
 				static_cast<unsigned long long>(print_clean));

@@ -57,3 +57,31 @@ def test_named_colours_saturate_like_the_reference():
         assert capi.host_lib().rt_host_named_colour(name.encode(), out) == 1
         assert list(out[:3]) == rgb and out[3] == 1.0
     assert capi.host_lib().rt_host_named_colour(b"not_a_colour", out) == 0
+
+
+def test_frame_digests_are_this_oracles():
+    """tests/golden/frame_digests.json (tools/gen_frame_digests.py) holds sha256 digests of the oracle's frames at BASELINE.json's
+    full sizes — what bench.py's `frame_matches_oracle` and the GPU suite's whole-frame checks compare against.  The small
+    entries are re-made here (config 1: plumbing size; config 2: 1920x1080x64, seconds on a few cores); every entry names the
+    contract it was made under and the workload string bench.py looks it up by."""
+    import hashlib
+    import json
+
+    import rt_amd
+    from tools.gen_frame_digests import TILT, WORKLOADS, workload_key
+
+    digests = json.loads((GOLDEN / "frame_digests.json").read_text())
+    assert set(digests) == set(WORKLOADS)
+    for key, (name, width, height, spp, tilt, partition) in WORKLOADS.items():
+        entry = digests[key]
+        assert entry["contract"] == "v4" and entry["workload"] == workload_key(name, width, height, spp, entry["max_bounces"], 1, tilt)
+        assert (entry["scene"], entry["width"], entry["height"], entry["spp"], entry["tilt"]) == (name, width, height, spp, tilt)
+        assert entry["partition"] == (list(partition) if partition else None) and len(entry["sha256"]) == 64
+    for key in ("config1", "config2"):
+        name, width, height, spp, tilt, partition = WORKLOADS[key]
+        scene = rt_amd.Scene.named(name).set_sampling(spp)
+        if tilt:
+            scene.set_camera(*TILT)
+        rgba, _, stats = oracle.render(scene.describe(width, height), width, height, seed=1, partition=partition, want_rgb=False)
+        assert hashlib.sha256(rgba.tobytes()).hexdigest() == digests[key]["sha256"], key
+        assert stats["segments"] == digests[key]["segments"]

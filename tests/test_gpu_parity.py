@@ -446,7 +446,21 @@ def test_partition_invariance_and_device_assemble(tracer, world, stripe):
 
 
 # ---- BASELINE.json's full sizes -----------------------------------------------------------------------------------------------
-def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
+def assert_digest(key, rgba, **facts):
+    """A packed frame (or stripe) against tests/golden/frame_digests.json: the ORACLE's frame, made in the build container by
+    tools/gen_frame_digests.py — whole frames at the full BASELINE sizes, whatever this host's core count allows the oracle to
+    re-render here.  bench.py checks the frame it timed against the same entries."""
+    import hashlib
+    import json
+
+    entry = json.loads((GOLDEN / "frame_digests.json").read_text())[key]
+    for name, value in facts.items():
+        assert entry[name] == value, (key, name, entry[name], value)
+    assert rgba.shape == (entry["rows"], entry["width"]) and rgba.dtype == np.uint32
+    assert hashlib.sha256(np.ascontiguousarray(rgba).tobytes()).hexdigest() == entry["sha256"], f"{key}: the frame is not the oracle's ({entry['workload']})"
+
+
+def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0, digest=None):
     """Render the full frame on the GPU; bit-check it against the oracle — the WHOLE frame when the host has the
     cores to render it in seconds (the GPU boxes do: the oracle runs at >100 Mrays/s there), otherwise the stripe
     subset `rank 0 of oracle_world`; check the rest through properties."""
@@ -473,6 +487,14 @@ def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
     table = distributed.local_row_table(height, oracle_world, 8)
     rows = np.nonzero(table[:, 0] == 0)[0]
     assert_bit_exact(rgba[rows], rgb[rows], want_rgba, want_rgb, f"{width}x{height} stripe subset")
+    if digest:  # the WHOLE frame against the oracle's digest
+        assert_digest(digest, rgba, width=width, height=height, spp=pod.samples_per_pixel, seed=seed)
+    # the very call bench.py times — rt_hip_render, default frame mode: the kernels store into the module's own page-locked frame
+    # and its carrier threads bring the pixels into the caller's PAGEABLE buffer — delivers the frame just checked
+    back_buffer = np.zeros((height, width), dtype=np.uint32)
+    _, _, drop_in_stats = tracer.render(pod, width, height, seed=seed, flags=flags, out=back_buffer)
+    assert np.array_equal(back_buffer, rgba), f"{width}x{height}: the drop-in call's frame differs from the device frame in {(back_buffer != rgba).sum()} pixels"
+    assert drop_in_stats["segments"] == stats["segments"]
     # properties over the whole frame
     assert np.all((rgba & 0xFF) == 0xFF)  # opaque alpha everywhere (colour.hpp:63-65)
     assert np.isfinite(rgb).all() and (rgb >= 0).all()
@@ -493,18 +515,18 @@ def check_full_size(tracer, scene, width, height, seed, oracle_world, flags=0):
 
 def test_config2_basic_1080p_64spp(tracer):
     """BASELINE config 2 at full size; the oracle covers 1/8 of the rows (every 8th stripe)."""
-    stats = check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(64), 1920, 1080, seed=1, oracle_world=8)
+    stats = check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(64), 1920, 1080, seed=1, oracle_world=8, digest="config2")
     assert stats["kernel"] == "small"
 
 
 def test_config3_dielectric_1080p_256spp(tracer):
     """BASELINE config 3 at full size (mg semantics: dielectrics shade as lambert); the oracle covers 1/32 of the rows."""
-    check_full_size(tracer, rt_amd.Scene.named("dielectric").set_sampling(256), 1920, 1080, seed=1, oracle_world=32)
+    check_full_size(tracer, rt_amd.Scene.named("dielectric").set_sampling(256), 1920, 1080, seed=1, oracle_world=32, digest="config3")
 
 
 def test_headline_basic_1080p_256spp(tracer):
     """The headline workload of bench.py; the oracle covers 1/32 of the rows."""
-    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(256), 1920, 1080, seed=1, oracle_world=32)
+    check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(256), 1920, 1080, seed=1, oracle_world=32, digest="headline")
 
 
 @pytest.mark.parametrize("name,tilted", [("basic_plane", False), ("dielectric_plane", False), ("basic_plane", True)])
@@ -517,7 +539,8 @@ def test_the_reference_scenes_with_their_plane_at_full_size(tracer, name, tilted
         scene.set_camera((0.2, 1.2, 3.0), (0.0, -0.15, -1.0))
         ivp = scene.describe(1920, 1080).inverse_view_projection[:]
         assert not (ivp[12] == 0.0 and ivp[13] == 0.0)
-    stats = check_full_size(tracer, scene, 1920, 1080, seed=1, oracle_world=32)
+    # (basic_plane through the tilted camera is bench.py's `interactive` workload: its whole frame has a digest)
+    stats = check_full_size(tracer, scene, 1920, 1080, seed=1, oracle_world=32, digest="interactive" if (name, tilted) == ("basic_plane", True) else None)
     assert stats["kernel"] == "small" and stats["plane_tests"] == stats["segments"]
 
 
@@ -533,6 +556,11 @@ def test_config4_basic_4k_tile_split(tracer):
 
         warnings.warn(f"test_config4_basic_4k_tile_split ran at {spp} spp, not BASELINE.json's 256: this host has {len(os.sched_getaffinity(0))} threads for the oracle")
     check_full_size(tracer, rt_amd.Scene.named("basic").set_sampling(spp), 3840, 2160, seed=1, oracle_world=16)
+    # config 4 AT ITS FULL 256 spp whatever the host: the whole 4K frame against the digest of the oracle's (10 ms of GPU)
+    full = rt_amd.Scene.named("basic").set_sampling(256).describe(3840, 2160)
+    frame, _, stats = tracer.render(full, 3840, 2160, seed=1)
+    assert_digest("config4", frame, width=3840, height=2160, spp=256, seed=1)
+    assert stats["primary_samples"] == 3840 * 2160 * 256
 
 
 @pytest.mark.parametrize("flags,kernel", [(0, "streamed"), (FORCE_TILED, "tiled")], ids=["auto", "tiled"])
@@ -583,6 +611,7 @@ def test_config5_synthetic_100k_full_size(tracer, flags, kernel):
     assert want_rgba.shape == (8, width)
     rows = slice(stripe * 8, stripe * 8 + 8)
     assert_bit_exact(rgba[rows], rgb[rows], want_rgba, want_rgb, f"synthetic-100k full size, rows {stripe * 8}..{stripe * 8 + 7} ({stats['kernel']})")
+    assert_digest("config5_stripe90", rgba[rows], width=width, height=height, spp=spp, seed=seed, partition=[stripe, 135, 8])
     assert len(np.unique(want_rgba)) > 1000  # the stripe does show the sphere field, not a flat colour
     # properties over the whole frame
     assert np.all((rgba & 0xFF) == 0xFF)
@@ -631,6 +660,36 @@ def test_waves_with_a_handful_of_rays_scan_together(tracer, count, width, height
         assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{count} spheres {width}x{height}x{spp}")
         assert stats["segments"] == want_stats["segments"]
     assert len(np.unique(want_rgba)) > 10
+
+
+@pytest.mark.parametrize("count,planes,width,height,spp", [(24, 0, 64, 36, 5), (40, 2, 97, 41, 20), (100, 1, 33, 17, 40), (300, 0, 160, 90, 17), (700, 3, 24, 13, 33), (64, 0, 320, 180, 64)])
+@pytest.mark.parametrize("flags", [0, SM], ids=["mg", "sm"])
+def test_the_resident_kernel_at_mid_sizes(tracer, count, planes, width, height, spp, flags):
+    """The LDS-resident kernel on scenes of a few dozen to 700 primitives — the gap between the two tuned ends — at 0 ulp: pixels of one
+    chunk (5 spp) and of several (17 .. 64 spp), planes behind the spheres, both scatter tables, a camera that is not axis-aligned,
+    twice in a row, and as one rank's share of a partition.  (Round 5 tried this kernel with the big-scene kernels' rolling items
+    against these very cases: bit-exact, and 4 to 10 times slower — an arrival atomic per item; profiles/r05/resident_rolling_ab.txt.)"""
+    rng = np.random.default_rng(count + spp)
+    spheres, materials, camera = _sphere_field(rng, count - planes)
+    plane_rows = [(0.0, 1.0, 0.0, 0.002, 0), (0.0, 0.0, 1.0, 30.0, 2), (1.0, 0.0, 0.0, 14.0, 1)][:planes]
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, plane_rows, materials, samples_per_pixel=spp, max_bounces=6, inverse_view_projection=ivp)
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=count, sm_materials=bool(flags & SM))
+    for _ in range(2):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=count, flags=flags, want_rgb=True)
+        assert stats["kernel"] == "resident"
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"{count} primitives ({planes} planes) {width}x{height}x{spp}")
+        assert stats["segments"] == want_stats["segments"]
+    assert len(np.unique(want_rgba)) > 10
+    # its share of a partition (what a rank of a multi-GPU frame renders) equals the same rows of the whole frame
+    import torch
+
+    tracer.upload(pod)
+    share = torch.zeros((rt_amd.padded_local_rows(height, 3, 4), width), dtype=torch.int32, device="cuda:0")
+    tracer.render_device(width, height, share.data_ptr(), seed=count, flags=flags, partition=(1, 3, 4), stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    owned = [y for y in range(height) if (y // 4) % 3 == 1]
+    assert np.array_equal(share.cpu().numpy().view(np.uint32)[: len(owned)], want_rgba[owned])
 
 
 def test_equal_distances_go_to_the_lowest_index_whichever_way_the_scan_runs(tracer):

@@ -82,8 +82,8 @@ def test_primary_rays_match_pinhole_model(size):
     pod = scene.describe(width, height)
     eye = np.array([0.0, 1.0, 3.0])
     for px, py in [(width / 2, height / 2), (0.0, 0.0), (width, height), (0.5, height - 0.5), (width * 0.25, height * 0.9)]:
-        o, d, pinhole = oracle_primary_ray_at(pod, width, height, px, py, want_form=True)
-        assert pinhole  # rt's camera, axis-aligned: the per-pixel base form
+        o, d, form = oracle_primary_ray_at(pod, width, height, px, py, want_form=True)
+        assert form == "pinhole"  # rt's camera, axis-aligned: the per-pixel base form
         want = analytic_primary_direction(px, py, width, height)
         # float32 inverse view-projection with near 0.01 / far 1000: ~1e-5 rad of direction error
         assert np.allclose(d, want, atol=5e-5), (px, py, d, want)
@@ -437,26 +437,46 @@ def test_one_step_serves_one_call():
     assert np.allclose(rgb[17, 11], want, rtol=1e-6)
 
 
-def test_a_camera_that_is_not_a_pinhole_takes_the_general_form_and_both_forms_agree():
+def test_the_three_camera_forms_agree_where_they_overlap():
+    """Primary rays come in three forms (oracle/cpu_ref.cpp make_frame): `pinhole` (rt's camera while axis-aligned: w constant over
+    the frame), `eye` (any perspective matrix: a tilted camera's float inverse has rounding noise in its w row — every frame of an
+    interactive session), `general` (no finite eye: an orthographic frustum).  Which one a matrix gets is decided from the matrix;
+    where two apply they must give the same rays to rounding."""
+    samples = ((0, 0, 0.0, 0.0), (160, 100, 2.0**23, 2.0**23), (319, 199, 2.0**24 - 1, 1.0), (7, 190, 123456.0, 2.0**24 - 1))
     scene = rt_amd.Scene.named("basic")
     pod = scene.describe(320, 200)
-    pinhole = [oracle.primary_ray(pod, 320, 200, x, y, ka, kb, want_form=True) for x, y, ka, kb in ((0, 0, 0.0, 0.0), (160, 100, 2.0**23, 2.0**23), (319, 199, 2.0**24 - 1, 1.0))]
-    assert all(form for _, _, form in pinhole)
-    # the same matrix with a w row that says "x matters" by one part in 10^12: the homogeneous form, one division per sample
+    pinhole = [oracle.primary_ray(pod, 320, 200, *sample, want_form=True) for sample in samples]
+    assert all(form == "pinhole" for _, _, form in pinhole)
+    # the same matrix with a w row that says "x matters" by one part in 10^12: no pinhole any more, still a perspective matrix
     m = list(pod.inverse_view_projection)
     m[12] = 1.0e-12 * m[15]
     for i, v in enumerate(m):
         pod.inverse_view_projection[i] = v
-    general = [oracle.primary_ray(pod, 320, 200, x, y, ka, kb, want_form=True) for x, y, ka, kb in ((0, 0, 0.0, 0.0), (160, 100, 2.0**23, 2.0**23), (319, 199, 2.0**24 - 1, 1.0))]
-    assert not any(form for _, _, form in general)
-    for (o1, d1, _), (o2, d2, _) in zip(pinhole, general):
-        assert np.allclose(d1, d2, atol=3e-7) and np.allclose(o1, o2, atol=3e-7)
-    # an orthographic frustum has a constant w and is no pinhole: parallel rays from different near points
+    eye = [oracle.primary_ray(pod, 320, 200, *sample, want_form=True) for sample in samples]
+    assert all(form == "eye" for _, _, form in eye)
+    for (o1, d1, _), (o2, d2, _) in zip(pinhole, eye):
+        assert np.allclose(d1, d2, atol=2e-7) and np.allclose(o1, o2, atol=3e-7)
+    # a camera that really is not axis-aligned: the eye form against screen_to_world in binary64 (camera.hpp:42-48), near and far
+    tilted = rt_amd.Scene.named("basic").set_camera((1.0, 2.0, 3.0), (0.3, -0.2, -1.0)).describe(320, 200)
+    big = np.array(list(tilted.inverse_view_projection), dtype=np.float64).reshape(4, 4)
+    assert big[3, 0] != 0.0 or big[3, 1] != 0.0  # the rounding noise that keeps it from being a pinhole
+    for x, y, ka, kb in samples:
+        o, d, form = oracle.primary_ray(tilted, 320, 200, x, y, ka, kb, want_form=True)
+        assert form == "eye"
+        px, py = x + ka * 2.0**-24, y + kb * 2.0**-24
+        ends = []
+        for depth in (0.0, 1.0):
+            v = big @ np.array([2.0 * px / 320 - 1.0, -2.0 * py / 200 + 1.0, depth, 1.0])
+            ends.append(v[:3] / v[3])
+        want = (ends[1] - ends[0]) / np.linalg.norm(ends[1] - ends[0])
+        assert np.allclose(d, want, atol=2e-7), (d, want)  # (the two-division float32 form of round 4 was good to 1e-5 here)
+        assert np.allclose(o, ends[0], atol=1e-6)
+    # an orthographic frustum has no eye: the homogeneous form — parallel rays from different near points
     ortho = rt_amd.Scene.named("basic").describe(320, 200)
     for i, v in enumerate([2.0, 0, 0, 0, 0, 1.25, 0, 1.0, 0, 0, -10.0, 3.0, 0, 0, 0, 1.0]):
         ortho.inverse_view_projection[i] = v
     (o1, d1, f1), (o2, d2, f2) = (oracle.primary_ray(ortho, 320, 200, x, y, want_form=True) for x, y in ((10, 20), (300, 180)))
-    assert not f1 and not f2
+    assert f1 == "general" and f2 == "general"
     assert np.array_equal(d1, d2) and np.allclose(d1, (0, 0, -1)) and not np.allclose(o1, o2)
 
 

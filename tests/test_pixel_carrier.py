@@ -32,6 +32,22 @@ def test_frames_arrive_whole_and_the_staging_frame_is_left_clean(tmp_path, helpe
     print(out.stdout.strip())
 
 
+def test_helpers_confined_to_fewer_cpus_than_threads_still_deliver_the_frame(tmp_path):
+    """the default frame mode twice degraded to "the caller's thread carried the frame alone" (+0.4 ms on the
+    headline) on a GPU box — helpers that exist but do not get to run.  Whatever keeps them off a CPU (an affinity mask that
+    squeezes seven spinning helpers, the caller's thread and the thread playing the device onto ONE CPU here; a cgroup's CPU-time
+    quota on the box), nothing may be lost or torn: every frame arrives whole, abandoned frames write nothing foreign, the
+    staging frame is left clean — only late.  (The carrier reports how many bands went early: rt_hip_phases.carrier_bands_early,
+    bench.py's drop_in_breakdown.bands_early.)"""
+    import os
+
+    exe = build(tmp_path, "carrier_confined")
+    one_cpu = {sorted(os.sched_getaffinity(0))[0]}
+    out = subprocess.run([str(exe), "7", "2"], capture_output=True, text=True, timeout=900, preexec_fn=lambda: os.sched_setaffinity(0, one_cpu))
+    assert out.returncode == 0 and out.stdout.startswith("OK"), out.stdout + out.stderr
+    print(out.stdout.strip())
+
+
 def test_thread_sanitizer_finds_nothing(tmp_path):
     """The portable build of the carrier (atomic word accesses instead of SSE2 lines) under -fsanitize=thread: the hand-over
     of a job between the caller's thread and the helpers, and every access to the two buffers."""

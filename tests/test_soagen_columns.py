@@ -33,6 +33,21 @@ def test_columns_of_a_real_soagen_table_are_read_up_to_size_and_no_further(tmp_p
     assert "11 spheres in capacity" in run.stdout  # padding rows existed (and were poisoned)
 
 
+@pytest.mark.gpu
+def test_real_soagen_columns_through_the_drop_in_call_on_the_gpu():
+    """real `soagen::table` memory — 32-byte aligned columns, padded capacity, padding poisoned — handed to
+    rt_hip_render on the GPU; the frame is the oracle's.  The program is built in the build container (Makefile:
+    oracle/_ref/soagen_columns, from tests/native/soagen_columns.cpp and the reference's vendor/soagen.hpp in place) and travels
+    to the GPU box as a binary."""
+    exe = ROOT / "oracle" / "_ref" / "soagen_columns"
+    if not exe.exists():
+        pytest.skip("oracle/_ref/soagen_columns was not built (the build container has the reference tree; run `make` there)")
+    run = subprocess.run([str(exe), "--gpu"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "OK:" in run.stdout, run.stdout + run.stderr
+    assert run.stdout.count("equals the oracle's") == 2 and "DIFFERS" not in run.stdout, run.stdout
+    assert "padding poisoned" in run.stdout
+
+
 def test_scene_check_is_usable_without_a_gpu_and_agrees_with_the_loader():
     """rt_hip_scene_check on the scenes the host side loads: accepted, and the fingerprint only depends on the columns."""
     import numpy as np
