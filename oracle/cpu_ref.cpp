@@ -35,8 +35,8 @@
 //                            pixel position — evaluated once per PIXEL at its corner, base_c = fmaf(d1_c, x,
 //                            fmaf(d2_c, y, d0_c)), and moved per SAMPLE by the jitter's numerators (ka, kb; u = k * 2^-24):
 //                            toward_c = fmaf(j1_c, ka, fmaf(j2_c, kb, base_c)), j = d * 2^-24; dir = normalize(toward);
-//                            origin_c = fmaf(kappa, toward_c, eye_c) — the near point, which lies on the line from the
-//                            eye at the fixed fraction kappa = near / (far - near) of the near-to-far vector.
+//                            origin_c = eye_c + toward_c — the vector carried is kappa * (far - near) = near - eye, the
+//                            near point lying on the line from the eye at the fixed fraction kappa = near / (far - near).
 //                            A PERSPECTIVE matrix that is no pinhole's in binary32 (a tilted camera: rounding noise in its
 //                            w row): all near-to-far lines pass through the eye E = Z.xyz / Z.w (Z = the depth column);
 //                            N' = N.xyz - E N.w, the homogeneous near point relative to it, is affine in the pixel
@@ -252,11 +252,11 @@ namespace
 		std::vector<material> materials;
 		uint32_t width, height;
 		float sx, sy; // 2 / W, 2 / H
-		// contract v4: primary rays of a pinhole camera (rt's: camera.hpp:122-137) — the near-to-far vector as an affine
-		// function of the pixel position (d0 + d1 x + d2 y), the jitter's share of it per numerator (j = d * 2^-24), and
-		// the near point as eye + kappa * (near-to-far); constants worked out in binary64
+		// contract v4: primary rays of a pinhole camera (rt's: camera.hpp:122-137) — the vector from the eye to the near
+		// point, kappa * (far - near), as an affine function of the pixel position (d0 + d1 x + d2 y), the jitter's share of
+		// it per numerator (j = d * 2^-24), and the eye; constants worked out in binary64
 		bool pinhole_rays;
-		float ray_d0[3], ray_d1[3], ray_d2[3], ray_j1[3], ray_j2[3], ray_eye[3], ray_kappa;
+		float ray_d0[3], ray_d1[3], ray_d2[3], ray_j1[3], ray_j2[3], ray_eye[3];
 		// a perspective matrix that is no pinhole's in binary32 (a tilted camera: its w row carries rounding noise): every
 		// near-to-far line still passes through ONE point, the eye E = Z.xyz / Z.w (Z = the matrix's depth column), and the
 		// homogeneous near point relative to it, N' = N.xyz - E N.w, is affine in the pixel position: the near-to-far
@@ -350,13 +350,13 @@ namespace
 					worst = std::fmax(worst, std::fmax(std::fabs(o1[c] - kappa * d1[c]), std::fabs(o2[c] - kappa * d2[c])));
 					scale = std::fmax(scale, std::fmax(std::fabs(o1[c]), std::fabs(o2[c])));
 				}
-				if (dd > 0.0 && std::isfinite(kappa) && worst <= 1.0e-5 * scale) // (a NaN anywhere fails the comparison)
+				if (dd > 0.0 && kappa >= 0x1.0p-20 && kappa <= 0x1.0p20 && worst <= 1.0e-5 * scale) // (a NaN anywhere fails a comparison; kappa = near / (far - near) scales the vector the kernels normalise, so its sign and size matter)
 				{
 					f.pinhole_rays = true;
-					f.ray_kappa = static_cast<float>(kappa);
 					for (int c = 0; c < 3; c++)
 					{
-						f.ray_d0[c] = static_cast<float>(d0[c]), f.ray_d1[c] = static_cast<float>(d1[c]), f.ray_d2[c] = static_cast<float>(d2[c]);
+						// (the vector the kernels carry is kappa * (far - near) = near - eye: the near point is then eye + it, one addition)
+					f.ray_d0[c] = static_cast<float>(kappa * d0[c]), f.ray_d1[c] = static_cast<float>(kappa * d1[c]), f.ray_d2[c] = static_cast<float>(kappa * d2[c]);
 						f.ray_j1[c] = f.ray_d1[c] * 0x1.0p-24f, f.ray_j2[c] = f.ray_d2[c] * 0x1.0p-24f;
 						f.ray_eye[c] = static_cast<float>(o0[c] - kappa * d0[c]);
 					}
@@ -411,7 +411,7 @@ namespace
 			{
 				const float base = std::fmaf(f.ray_d1[c], fx, std::fmaf(f.ray_d2[c], fy, f.ray_d0[c])); // once per pixel
 				t[c] = std::fmaf(f.ray_j1[c], ka, std::fmaf(f.ray_j2[c], kb, base));
-				o[c] = std::fmaf(f.ray_kappa, t[c], f.ray_eye[c]);
+				o[c] = f.ray_eye[c] + t[c];
 			}
 			return { origin, normalize(toward) }; // :190-193
 		}

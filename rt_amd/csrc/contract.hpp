@@ -50,6 +50,7 @@ namespace rt_hip
 	__device__ __forceinline__ float sqrt_rn_where(float x, bool) { return __builtin_amdgcn_sqrtf(x); }
 	__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }
 	__device__ __forceinline__ float rcp_rn(float x) { return __builtin_amdgcn_rcpf(x); }
+	__device__ __forceinline__ float rcp_in_band(float x) { return __builtin_amdgcn_rcpf(x); }
 	__device__ __forceinline__ float inv_sqrt_rn(float x) { return __builtin_amdgcn_rsqf(x); }
 	__device__ __forceinline__ float inv_sqrt_in_band(float x) { return __builtin_amdgcn_rsqf(x); }
 	__device__ __forceinline__ float divide(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -115,6 +116,9 @@ namespace rt_hip
 		}
 		return q;
 	}
+
+	// rcp_rn for an argument the CALLER has proved to lie in the band (|x| in 2^-60 .. 2^60): no check, no fallback
+	__device__ __forceinline__ float rcp_in_band(float x) { return rcp_core(x, __builtin_amdgcn_rcpf(x)); }
 
 	// ---- the reciprocal square root of normalize(): contract v3 -----------------------------------------------------
 	// v2 defined normalize() through 1.0f / sqrtf(x) and kept BOTH roundings: a quarter-rate v_rsq AND a quarter-rate

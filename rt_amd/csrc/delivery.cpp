@@ -27,6 +27,25 @@ namespace rt_hip
 		constexpr size_t copy_band_bytes = 256u << 10;
 		constexpr size_t small_frame_bytes = 128u << 10; // frames up to this size are not worth waking anybody for
 
+		// a wait that may be long (the peer it waits for can have been descheduled, or its cgroup throttled): spin briefly, then
+		// give the CPU away between looks — the waiter burns the same quota the one it waits for needs
+		template <typename Done>
+		inline void wait_until(Done done)
+		{
+			for (unsigned spins = 0; !done(); spins++)
+			{
+				if (spins < 4096u)
+				{
+#ifdef RT_HIP_CARRIER_SSE2
+					_mm_pause();
+#endif
+					asm volatile("" ::: "memory");
+				}
+				else
+					std::this_thread::yield();
+			}
+		}
+
 		inline void relax()
 		{
 #ifdef RT_HIP_CARRIER_SSE2
@@ -262,8 +281,7 @@ namespace rt_hip
 	void pixel_carrier::close()
 	{
 		open_.store(false, std::memory_order_seq_cst);
-		while (inside_.load(std::memory_order_seq_cst) != 0)
-			relax();
+		wait_until([&] { return inside_.load(std::memory_order_seq_cst) == 0; });
 	}
 
 	// What every thread does with a frame in flight.  A thread keeps a handful of bands OPEN at a time and sweeps over them,
@@ -439,8 +457,7 @@ namespace rt_hip
 		early_bands_ = bands_done_.load(std::memory_order_acquire);
 		state_.store(drained, std::memory_order_release);
 		work();
-		while (bands_done_.load(std::memory_order_acquire) != bands_)
-			relax();
+		wait_until([&] { return bands_done_.load(std::memory_order_acquire) == bands_; });
 		close();
 		in_flight_ = false;
 	}
@@ -456,9 +473,10 @@ namespace rt_hip
 
 	void pixel_carrier::copy(void* to, const void* from, size_t bytes)
 	{
-		if (in_flight_ || !bytes)
+		if (!bytes)
 			return;
-		if (threads_.empty() || bytes <= copy_band_bytes)
+		// (a frame in flight owns the helpers: the caller's thread copies alone — never "nothing copied, nothing said")
+		if (in_flight_ || threads_.empty() || bytes <= copy_band_bytes)
 		{
 			std::memcpy(to, from, bytes);
 			return;
@@ -474,8 +492,7 @@ namespace rt_hip
 		bands_done_.store(0, std::memory_order_relaxed);
 		post();
 		work();
-		while (bands_done_.load(std::memory_order_acquire) != bands_)
-			relax();
+		wait_until([&] { return bands_done_.load(std::memory_order_acquire) == bands_; });
 		close();
 	}
 }

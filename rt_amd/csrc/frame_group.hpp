@@ -67,6 +67,11 @@ namespace rt_hip
 		std::atomic<uint32_t> magic; // stored last by the creator
 		uint32_t world;
 		int32_t creator_pid; // rank 0's process: a block whose creator is gone (or whose join is over) is a leftover, not this group's
+		// ... as far as a reader can tell: a pid means something only inside its PID namespace, and may be in use again by another
+		// process.  The creator's namespace (inode of /proc/self/ns/pid) and its start time (field 22 of /proc/<pid>/stat,
+		// clock ticks since boot) say whether "no such process" is to be believed and whether "such a process" is still THAT one.
+		uint64_t creator_pidns;
+		uint64_t creator_start;
 		alignas(64) std::atomic<uint64_t> joined;
 		alignas(64) std::atomic<uint64_t> entered;	 // + 1 per rank per frame: everybody is inside rt_hip_render
 		alignas(64) std::atomic<uint64_t> nonce_set; // + 1 per rank per buffer check: rank 0's mark is in the buffer
@@ -175,6 +180,8 @@ namespace rt_hip
 			{
 				block->world = world;
 				block->creator_pid = static_cast<int32_t>(getpid());
+				block->creator_pidns = pid_namespace();
+				block->creator_start = process_start_time(static_cast<int32_t>(getpid()));
 				block->magic.store(frame_group_magic, std::memory_order_release);
 			}
 			else
@@ -307,6 +314,42 @@ namespace rt_hip
 			const char* const after_name = std::strrchr(text, ')'); // "pid (comm) S ...": comm may contain anything but ends at the LAST ')'
 			return !(after_name && after_name[1] == ' ' && (after_name[2] == 'Z' || after_name[2] == 'X'));
 		}
+		// 0 = cannot be told
+		static uint64_t pid_namespace()
+		{
+			struct stat st;
+			return stat("/proc/self/ns/pid", &st) == 0 ? static_cast<uint64_t>(st.st_ino) : 0u;
+		}
+		static uint64_t process_start_time(int32_t pid)
+		{
+			char path[64], text[1024];
+			std::snprintf(path, sizeof(path), "/proc/%d/stat", static_cast<int>(pid));
+			const int fd = open(path, O_RDONLY | O_CLOEXEC);
+			if (fd < 0)
+				return 0u;
+			const ssize_t n = read(fd, text, sizeof(text) - 1);
+			(void)close(fd);
+			if (n <= 0)
+				return 0u;
+			text[n] = '\0';
+			const char* at = std::strrchr(text, ')'); // fields 3.. follow the LAST ')' (comm may contain anything)
+			for (int field = 2; at && field < 22; field++)
+				at = std::strchr(at + 1, ' ');
+			return at ? std::strtoull(at + 1, nullptr, 10) : 0u;
+		}
+		// the creator of a found block is gone: only a reader in the creator's PID namespace can say so (from another namespace a
+		// live creator looks like "no such process": such a reader relies on joined >= world, `broken` and its own deadline), and a
+		// process that exists under that pid but started at another time is not the creator
+		static bool creator_is_gone(const frame_group_block* found)
+		{
+			const uint64_t mine = pid_namespace();
+			if (!mine || !found->creator_pidns || mine != found->creator_pidns)
+				return false;
+			if (!process_exists(found->creator_pid))
+				return true;
+			const uint64_t started = process_start_time(found->creator_pid);
+			return started && found->creator_start && started != found->creator_start;
+		}
 		// A block found under the group's name that cannot be THIS group's: initialised, and either its creator is gone or
 		// everybody of ITS world had joined (a live group removes its name at that moment) or it was broken.
 		static bool is_leftover_fd(int fd)
@@ -316,7 +359,7 @@ namespace rt_hip
 				return false;
 			const frame_group_block* const found = static_cast<const frame_group_block*>(mapping);
 			const bool initialised = found->magic.load(std::memory_order_acquire) == frame_group_magic;
-			const bool leftover = initialised && (!process_exists(found->creator_pid) || found->joined.load(std::memory_order_acquire) >= found->world || found->broken.load(std::memory_order_acquire) != 0);
+			const bool leftover = initialised && (creator_is_gone(found) || found->joined.load(std::memory_order_acquire) >= found->world || found->broken.load(std::memory_order_acquire) != 0);
 			(void)munmap(mapping, sizeof(frame_group_block));
 			return leftover;
 		}

@@ -224,7 +224,6 @@ namespace rt_hip
 			uint32_t window, window_end;
 			uint32_t sample;	 // [INDEXED kernels only] index of the sample in flight
 			uint32_t sample_end; // [INDEXED kernels only] one past the last sample of the item in flight
-			uint32_t bounces_left; // bounces the path may still make AFTER the segment in flight
 		};
 
 		// image row of row `local_row` of this rank's compact buffer (rt_hip_partition).  All branches are wave-uniform.
@@ -532,25 +531,15 @@ namespace rt_hip
 			// what the lane does in the current trip:
 			//   free    - between items                       restart - has a sample to start (needs a primary ray)
 			//   trace   - has a ray: closest-hit query next    retired - the queue ran dry
-			enum : uint32_t { lane_free, lane_restart, lane_trace, lane_retired };
-#ifndef RT_HIP_MODE_MASKS
-			uint32_t mode = lane_free; // the mode as a number in a vector register
-#define RT_HIP_IS(m) (mode == (m))
+			// ONE register says both: 0 free, 1 restart, 3 retired, and from lane_trace (4) upwards "tracing, and the path may still
+			// make (mode - 4) bounces after the segment in flight" — the bounce count of `if (!(max_bounces--)) return {}` (:157).  A
+			// restart sets both with one move, a bounce takes one off, and the lane that would go below 4 has run out of bounces.
+			// (Round 4 tried the mode as three lane MASKS kept in scalar registers instead of a number in a vector register: same
+			// vector instruction count, 42 % more scalar ones, 2.64 -> 2.85 ms — profiles/r04/ab_mode_masks.txt, HISTORY.md.)
+			enum : uint32_t { lane_free = 0, lane_restart = 1, lane_retired = 3, lane_trace = 4 };
+			uint32_t mode = lane_free;
+#define RT_HIP_IS(m) ((m) == lane_trace ? mode >= lane_trace : mode == (m))
 #define RT_HIP_BECOME(m) (mode = (m))
-#else
-			// Round 4's one structural experiment ("fewer lane modes"), NOT adopted: the mode not as a per-lane
-			// NUMBER that every use compares (a v_cmp per question, a v_cndmask / v_mov per change) but as three lane MASKS, which
-			// the compiler keeps as 64-bit scalar pairs across loop trips and combines on the scalar unit.  Same frames; the
-			// vector instruction count did not move (2.204 G against 2.207 G per headline launch: the compares were already
-			// folded into the branches' masks), the scalar one rose by 42 % (1.264 G against 0.891 G) — and the kernel went
-			// from 2.64 to 2.85 ms: the scalar unit is NOT free here, its instructions sit on the loop's critical path between
-			// the vector ones (profiles/r04/ab_mode_masks.txt).  Kept behind this switch for the record.
-			bool in_trace = false, in_restart = false, in_retired = false;
-			const auto mode_is = [&](uint32_t m) { return m == lane_trace ? in_trace : m == lane_restart ? in_restart : m == lane_retired ? in_retired : !(in_trace || in_restart || in_retired); };
-			const auto become = [&](uint32_t m) { in_trace = m == lane_trace, in_restart = m == lane_restart, in_retired = m == lane_retired; };
-#define RT_HIP_IS(m) mode_is(m)
-#define RT_HIP_BECOME(m) become(m)
-#endif
 
 			// all items of a tile are in: fold the chunk sums of each pixel in chunk order and write it (:195-200)
 			const auto fold_tile = [&](const float* sums, uint32_t x0, uint32_t y0)
@@ -830,7 +819,7 @@ namespace rt_hip
 				}
 
 				bool shade = false;
-				vec3 normal, hit_pos; // meaningful only where `shade` holds: deliberately not initialised
+				vec3 normal; // meaningful only where `shade` holds: deliberately not initialised
 				float4 shading;
 				uint32_t scatter_kind = scatter_lambert;
 				if (tracing)
@@ -944,7 +933,9 @@ namespace rt_hip
 					else
 					{
 						shade = true;
-						hit_pos = ray_at(st.origin, st.dir, distance);
+						// r.at(t): where the scattered ray starts (:122,139).  The lane is done with the old origin — it goes straight
+						// into the ray's registers (as a value of its own it was copied there, three moves per scatter, after the hand-out).
+						st.origin = ray_at(st.origin, st.dir, distance);
 						if (NS > 0)
 						{
 							RT_HIP_REGION(3); // hit: lookups + normal
@@ -963,7 +954,7 @@ namespace rt_hip
 								// normalisation altogether)
 								if (NP > 0)
 									asm volatile("; hit: some lane hit a sphere" ::: "memory");
-								normal = normalize(hit_pos - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
+								normal = normalize(st.origin - vec3{ g.x, g.y, g.z }); // direction(center, r.at(t)) (:85)
 							}
 						}
 					}
@@ -1124,7 +1115,9 @@ namespace rt_hip
 					vec3 toward; // the vector whose direction the new ray takes (set on both paths below)
 					// dot(toward, toward).  (sm's dielectric_scatter does not normalise what it returns: its lanes leave the 1 here,
 					// whose reciprocal square root is 1, and x * 1 is x for every x.)
-					float toward2 = 1.0f;
+					float toward2;
+					if (SM)
+						toward2 = 1.0f;
 					if (shade && SM && scatter_kind == scatter_dielectric)
 					{
 						// dielectric_scatter, sm_ray_tracer.cpp:181-219 (refract :161-172, schlick :174-179); shading.w = the
@@ -1158,9 +1151,8 @@ namespace rt_hip
 						st.counter = counter; // random<float>(): one step, its first draw
 						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
-						st.origin = hit_pos;
-						const bool dead = st.bounces_left == 0; // the next trace() call would return {} at :157-158
-						st.bounces_left--;
+						const bool dead = mode == lane_trace; // no bounce left: the next trace() call would return {} at :157-158
+						mode--;
 						if (dead)
 							end_sample({ 0.0f, 0.0f, 0.0f });
 					}
@@ -1206,13 +1198,12 @@ namespace rt_hip
 							}
 						}
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z }; // attenuation * trace(...) (:171)
-						st.origin = hit_pos;
 						toward = scatter;
 						st.counter = counter;
 						// absorbed, or the next trace() call would return {} at :157-158 (`if (!(max_bounces--))`: the count is kept
 						// as the bounces still allowed after the segment in flight, and only a bounce touches it)
-						const bool dead = absorbed || st.bounces_left == 0;
-						st.bounces_left--;
+						const bool dead = absorbed || mode == lane_trace;
+						mode--; // (a dead lane's mode is set by end_sample right below)
 						if (dead)
 						{
 							RT_HIP_REGION(12); // absorbed or out of bounces: the sample is worth nothing
@@ -1244,7 +1235,7 @@ namespace rt_hip
 							// lives on its scalar registers, a spill per lane mask.
 							toward = { fma(p.ray_j1[0], jx, fma(p.ray_j2[0], jy, st.base_x)), fma(p.ray_j1[1], jx, fma(p.ray_j2[1], jy, st.base_y)),
 									   fma(p.ray_j1[2], jx, fma(p.ray_j2[2], jy, st.base_z)) };
-							st.origin = { fma(p.ray_kappa, toward.x, p.ray_eye[0]), fma(p.ray_kappa, toward.y, p.ray_eye[1]), fma(p.ray_kappa, toward.z, p.ray_eye[2]) };
+							st.origin = { p.ray_eye[0] + toward.x, p.ray_eye[1] + toward.y, p.ray_eye[2] + toward.z }; // (toward = near - eye)
 						}
 						else if (EYE_ONLY || p.eye_form) // (wave-uniform)
 						{
@@ -1255,10 +1246,18 @@ namespace rt_hip
 							toward = { fma(p.eye_jq1[0], jx, fma(p.eye_jq2[0], jy, st.base_x)), fma(p.eye_jq1[1], jx, fma(p.eye_jq2[1], jy, st.base_y)),
 									   fma(p.eye_jq1[2], jx, fma(p.eye_jq2[2], jy, st.base_z)) };
 							const float ws = fma(p.eye_jw1, jx, fma(p.eye_jw2, jy, st.base_w));
-							const float inv = rcp_rn(ws);
+							const bool plain = p.eye_form == 2u; // (wave-uniform) the host has shown ws in the band and N.w F.w > 0 for the whole frame
+							float inv;
+							if (plain)
+								inv = rcp_in_band(ws);
+							else
+							{
+								asm volatile("; restart: the guarded reciprocal" ::: "memory");
+								inv = rcp_rn(ws);
+							}
 							st.origin = { fma(toward.x, inv, p.eye_e[0]), fma(toward.y, inv, p.eye_e[1]), fma(toward.z, inv, p.eye_e[2]) };
 							// far - near = s N' |Z.w| / (N.w F.w): s N' unless the near and far points lie on different sides of w = 0
-							if (__builtin_amdgcn_ballot_w64(ws * (ws + p.eye_zws) < 0.0f) != 0)
+							if (!plain && __builtin_amdgcn_ballot_w64(ws * (ws + p.eye_zws) < 0.0f) != 0)
 							{
 								asm volatile("; restart: some lane's near and far points straddle w = 0" ::: "memory");
 								if (ws * (ws + p.eye_zws) < 0.0f)
@@ -1289,9 +1288,8 @@ namespace rt_hip
 						}
 						toward2 = dot(toward, toward);
 						st.throughput = { 1.0f, 1.0f, 1.0f };
-						st.bounces_left = p.max_bounces - 1u;
 						st.counter = counter;
-						RT_HIP_BECOME(lane_trace);
+						mode = lane_trace + (p.max_bounces - 1u); // tracing, max_bounces - 1 bounces to go after the primary segment
 					}
 					if (shade || restart)
 					{

@@ -74,14 +74,14 @@ namespace rt_hip
 		//   base_c   = fma(ray_d1[c], x, fma(ray_d2[c], y, ray_d0[c]))          once per pixel (x, y: its column and row)
 		//   toward_c = fma(ray_j1[c], ka, fma(ray_j2[c], kb, base_c))           per sample; (ka, kb) = the jitter's numerators,
 		//                                                                        ray_j = ray_d * 2^-24
-		//   origin_c = fma(ray_kappa, toward_c, ray_eye[c])                     the near point: eye + near/(far-near) of the way
+		//   origin_c = ray_eye[c] + toward_c                                    the near point (ray_d holds kappa * (far - near)
+		//                                                                        = near - eye, kappa = near / (far - near))
 		// The scalar-register kernels are built for ONE form; mx .. k_far above serve the preview and any other matrix (an
 		// orthographic or sheared frustum, a w that varies over the frame: the homogeneous form with one division per sample).
 		uint32_t pinhole;
 		float ray_d0[3], ray_d1[3], ray_d2[3];
 		float ray_j1[3], ray_j2[3];
 		float ray_eye[3];
-		float ray_kappa;
 		// eye_form != 0: the matrix is a PERSPECTIVE one (its depth column Z has a finite point E = Z.xyz / Z.w: the eye every
 		// near-to-far line passes through) — what the general-camera kernels use for a camera that is not axis-aligned.  With
 		// N = the homogeneous near point, N' = N.xyz - E N.w and s = sign(-Z.w), both s N' and s N.w are affine in the pixel
@@ -91,7 +91,7 @@ namespace rt_hip
 		//   origin_c = fma(t_c, 1 / ws, eye_e[c]);   toward = t, negated if ws * (ws + eye_zws) < 0   (= N.w F.w < 0)
 		// One division per sample and no far point.  A matrix without a finite eye (an orthographic frustum) takes the
 		// homogeneous form from mx .. k_far above.
-		uint32_t eye_form;
+		uint32_t eye_form; // 1 as above; 2: additionally s N.w and s F.w keep one sign and stay deep inside the reciprocal's band over the whole frame (render.hip): no guard, no flip
 		float eye_q0[3], eye_q1[3], eye_q2[3];
 		float eye_jq1[3], eye_jq2[3];
 		float eye_w0, eye_w1, eye_w2, eye_jw1, eye_jw2;
@@ -190,7 +190,9 @@ namespace rt_hip
 #endif
 	constexpr uint32_t resident_scalar_scan_from = RT_HIP_RESIDENT_SCALAR_FROM; // spheres from which the resident kernel scans through the scalar cache (kernels.hip)
 	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
-	constexpr uint32_t streamed_from_primitives = 704; // ... which the launch code prefers up to this many
+	constexpr uint32_t streamed_from_primitives = 1024; // ... which the launch code prefers up to this many (round 5: all it can hold — since its sphere
+													   // scan goes through the scalar cache it is ahead of the streamed kernel's rolling items up to there:
+													   // 1000 spheres x 64 spp 43.4 against 49.1 ms, 700: 29.9 against 34.7; profiles/r05/resident_vs_streamed.txt)
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
 	// what a context remembers between launches: workgroups per CU that stay resident, for the persistent (big-scene) kernels

@@ -87,7 +87,9 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 		for (f.stripe_shift = 0; (1u << f.stripe_shift) != p.stripe_rows; f.stripe_shift++)
 		{}
 	f.samples_per_pixel = ctx->samples_per_pixel;
-	f.max_bounces = ctx->max_bounces;
+	// (the kernels keep "tracing" and the bounces still allowed in one word, lane_trace + count: a count of 2^30 is as good as any
+	// larger one — no path of a frame that ever finishes is that long)
+	f.max_bounces = std::min<uint32_t>(ctx->max_bounces, 1u << 30);
 	const frame_keys keys = make_frame_keys(seed);
 	f.frame_key_a = keys.a;
 	f.frame_key_b = keys.b;
@@ -135,6 +137,22 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 			f.eye_jw1 = f.eye_w1 * 0x1.0p-24f, f.eye_jw2 = f.eye_w2 * 0x1.0p-24f;
 			f.eye_zws = static_cast<float>(sign * zw);
 			f.eye_form = 1u;
+			// eye_form 2: over the whole frame s N.w and s N.w + s Z.w (= s F.w) keep ONE sign and stay far inside the band of the
+			// kernels' unguarded reciprocal (2^-60 .. 2^60) — both are affine in the pixel position, so their extremes sit at the
+			// frame's corners.  Then no lane ever needs the reciprocal's guard or the "near and far straddle w = 0" flip, and the
+			// kernels skip both (same bits: the guarded forms are identities there).  Every camera rt can make is such a one.
+			bool plain = true;
+			double first_w = 0.0;
+			for (int corner = 0; corner < 4 && plain; corner++)
+			{
+				const double x = (corner & 1) ? static_cast<double>(width) : 0.0, y = (corner & 2) ? static_cast<double>(height) : 0.0;
+				const double ws = sign * (n0w + n1w * x + n2w * y), fs = ws + sign * zw;
+				if (corner == 0)
+					first_w = ws;
+				plain = std::fabs(ws) >= 0x1.0p-50 && std::fabs(ws) <= 0x1.0p50 && std::fabs(fs) >= 0x1.0p-50 && std::fabs(fs) <= 0x1.0p50 && (ws > 0.0) == (first_w > 0.0) && (ws > 0.0) == (fs > 0.0);
+			}
+			if (plain)
+				f.eye_form = 2u;
 		}
 	}
 	f.pinhole = 0u;
@@ -159,13 +177,13 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 			worst = std::fmax(worst, std::fmax(std::fabs(o1[c] - kappa * d1[c]), std::fabs(o2[c] - kappa * d2[c])));
 			scale = std::fmax(scale, std::fmax(std::fabs(o1[c]), std::fabs(o2[c])));
 		}
-		if (dd > 0.0 && std::isfinite(kappa) && worst <= 1.0e-5 * scale) // (a NaN anywhere fails the comparison)
+		if (dd > 0.0 && kappa >= 0x1.0p-20 && kappa <= 0x1.0p20 && worst <= 1.0e-5 * scale) // (a NaN anywhere fails a comparison; kappa = near / (far - near) scales the vector the kernels normalise, so its sign and size matter)
 		{
 			f.pinhole = 1u;
-			f.ray_kappa = static_cast<float>(kappa);
 			for (int c = 0; c < 3; c++)
 			{
-				f.ray_d0[c] = static_cast<float>(d0[c]), f.ray_d1[c] = static_cast<float>(d1[c]), f.ray_d2[c] = static_cast<float>(d2[c]);
+				// (the vector the kernels carry is kappa * (far - near) = near - eye: the near point is then eye + it, one addition)
+					f.ray_d0[c] = static_cast<float>(kappa * d0[c]), f.ray_d1[c] = static_cast<float>(kappa * d1[c]), f.ray_d2[c] = static_cast<float>(kappa * d2[c]);
 				f.ray_j1[c] = f.ray_d1[c] * 0x1.0p-24f, f.ray_j2[c] = f.ray_d2[c] * 0x1.0p-24f;
 				f.ray_eye[c] = static_cast<float>(o0[c] - kappa * d0[c]);
 			}

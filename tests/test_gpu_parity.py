@@ -154,16 +154,15 @@ def test_frame_is_bit_exact(tracer, planes_scene, name, width, height, spp, boun
         expected_kernel = "streamed"  # (every big scene, whatever its sample count: profiles/r03/tiled_vs_streamed.txt)
     elif flags == 0 and pod.n_spheres >= 1 and pod.n_planes <= 3 and primitives <= 8:
         expected_kernel = "small"  # (round 4: up to three planes ride in scalar registers behind the spheres)
-    elif flags == 0 and primitives > 704:
-        expected_kernel = "streamed"  # (the resident kernel holds up to 1024 primitives; the launch code prefers it up to 704)
-    else:
+    else:  # (the resident kernel holds up to 1024 primitives, and since round 5 the launch code prefers it all the way: kernels.hpp)
         expected_kernel = "resident"
     assert stats["kernel"] == expected_kernel
 
 
 def test_projective_matrix_with_varying_w_takes_the_per_sample_division(tracer):
-    """A camera built like the reference's has a constant w per frame (the host takes 1/w once); any other
-    inverse view-projection must go through the per-sample reciprocal and still match the oracle bit for bit."""
+    """A camera built like the reference's has a constant w per frame; a perspective matrix whose w depends on x and y — here
+    strongly enough to change sign inside the frame: near and far points straddle w = 0 for some pixels — goes through the eye
+    form with its guarded reciprocal and the direction flip (frame_params::eye_form 1) and still matches the oracle bit for bit."""
     scene = rt_amd.Scene.named("basic").set_sampling(4)
     pod = scene.describe(96, 54)
     m = np.array(pod.inverse_view_projection[:], dtype=np.float32).reshape(4, 4)
@@ -175,6 +174,24 @@ def test_projective_matrix_with_varying_w_takes_the_per_sample_division(tracer):
         # (round 4: such a matrix keeps the scalar-register kernel — its general-camera build)
         assert stats["kernel"] == ("resident" if flags & FORCE_RESIDENT else "small")
         assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, "non-uniform w")
+
+
+def test_an_orthographic_frustum_has_no_eye_and_takes_the_homogeneous_form(tracer):
+    """The scalar-register kernels are built for cameras with an eye (the pinhole form; the eye form of any other perspective
+    matrix).  A matrix whose depth column has no finite point — an orthographic frustum, nothing rt's camera can produce, but
+    the C ABI takes any matrix — goes through the homogeneous near / far points in the LDS-resident kernel, bit-exact."""
+    scene = rt_amd.Scene.named("basic").set_sampling(6)
+    pod = scene.describe(120, 68)
+    ortho = [2.4, 0, 0, 0.0, 0, 1.35, 0, 1.0, 0, 0, -12.0, 3.0, 0, 0, 0, 1.0]  # x in -2.4..2.4, y in -0.35..2.35, z from 3 to -9, w = 1
+    pod.inverse_view_projection = (C.c_float * 16)(*ortho)
+    _, _, form = oracle.primary_ray(pod, 120, 68, 60, 34, want_form=True)
+    assert form == "general"
+    for flags in (0, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, FORCE_STREAMED):
+        got_rgba, got_rgb, stats = tracer.render(pod, 120, 68, seed=5, flags=flags, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, 120, 68, seed=5)
+        assert stats["kernel"] == ("streamed" if flags == FORCE_STREAMED else "resident")
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"orthographic frustum, flags {flags}")
+        assert stats["segments"] == want_stats["segments"] and len(np.unique(want_rgba)) > 50
 
 
 def test_a_camera_that_is_not_axis_aligned_keeps_the_scalar_register_kernel(tracer):
@@ -316,6 +333,37 @@ def test_random_scenes_are_bit_exact(tracer, case):
         assert same.all(), f"case {case} flags {flags} ({stats['kernel']}): {(~same).any(axis=-1).sum()} pixels differ"
         assert np.array_equal(got_rgba, want_rgba), f"case {case} flags {flags}"
         assert stats["segments"] == want_stats["segments"]
+
+
+def test_a_published_sum_keeps_its_value_until_the_store_has_read_it(tracer):
+    """Regression pin (profiles/r04/case0_bisect.txt).  The rolling kernels hand a chunk sum to another wave with ONE
+    hand-written `global_store_dwordx4 ... sc1` (kernels.hip publish_sum).  A VMEM store of more than 64 bits reads its data
+    registers AFTER issue; the compiler pads its own stores against the gfx940+ "VMEM store data hazard", but cannot see into
+    inline assembly: in round 4 the sm kernels' next instruction recycled the value's upper half for an address and z arrived
+    as a pointer's low word — on exactly this scene (case 0 of the random scenes: 3 spheres, 1 plane, 59 x 68, 32 spp = two
+    chunks per pixel) under the sm table with the streamed and the tiled kernel.  The two wait states behind the store are part
+    of it; this test holds the scene and the two launches by name, whole chunks and runs of samples."""
+    rng = np.random.default_rng(1000)
+    spheres, planes, materials, camera = random_scene(rng)
+    width, height = int(rng.integers(17, 140)), int(rng.integers(9, 90))
+    spp, bounces = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+    assert (len(spheres), len(planes), width, height, spp, bounces) == (3, 1, 59, 68, 32, 7)  # the scene of the record
+    ivp = camera.describe(width, height).inverse_view_projection[:]
+    pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=spp, max_bounces=bounces, inverse_view_projection=ivp)
+    seed = int(rng.integers(0, 2**63))
+    want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=seed, sm_materials=True)
+    WHOLE, HALF = capi.RT_HIP_FLAG_FORCE_WHOLE_CHUNKS, capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS
+    for flags in (SM | FORCE_STREAMED, SM | FORCE_TILED, SM | FORCE_STREAMED | WHOLE, SM | FORCE_TILED | WHOLE):
+        for _ in range(3):
+            got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
+            assert np.isfinite(got_rgb).all() and np.abs(got_rgb).max() < 1.0e6, f"flags {flags}: a sum arrived as something else"
+            assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"case 0, flags {flags} ({stats['kernel']})")
+            assert stats["segments"] == want_stats["segments"]
+    # (the mg table on the same launches, with items smaller than a chunk: every sample's value goes through the same store)
+    want_rgba, want_rgb, _ = oracle.render(pod, width, height, seed=seed)
+    for flags in (FORCE_STREAMED | HALF, FORCE_TILED | HALF):
+        got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=seed, flags=flags, want_rgb=True)
+        assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"case 0, flags {flags} ({stats['kernel']})")
 
 
 @pytest.mark.parametrize("case", range(6))
