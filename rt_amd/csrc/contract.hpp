@@ -51,6 +51,7 @@ namespace rt_hip
 	__device__ __forceinline__ float sqrt_rn(float x) { return __builtin_amdgcn_sqrtf(x); }
 	__device__ __forceinline__ float rcp_rn(float x) { return __builtin_amdgcn_rcpf(x); }
 	__device__ __forceinline__ float rcp_in_band(float x) { return __builtin_amdgcn_rcpf(x); }
+	__device__ __forceinline__ float rcp_rn_not_tiny_where(float x, bool) { return __builtin_amdgcn_rcpf(x); }
 	__device__ __forceinline__ float inv_sqrt_rn(float x) { return __builtin_amdgcn_rsqf(x); }
 	__device__ __forceinline__ float inv_sqrt_in_band(float x) { return __builtin_amdgcn_rsqf(x); }
 	__device__ __forceinline__ float divide(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
@@ -119,6 +120,21 @@ namespace rt_hip
 
 	// rcp_rn for an argument the CALLER has proved to lie in the band (|x| in 2^-60 .. 2^60): no check, no fallback
 	__device__ __forceinline__ float rcp_in_band(float x) { return rcp_core(x, __builtin_amdgcn_rcpf(x)); }
+
+	// == 1.0f / x in every lane where `wanted` holds, for a caller that has proved |x| >= 2^-60 or NaN there (other lanes get an
+	// unspecified value).  The band's lower end is the caller's, so the guard is ONE comparison — is |x| huge, infinite or NaN —
+	// where in_fast_band() takes a mask, an add and a compare.
+	__device__ __forceinline__ float rcp_rn_not_tiny_where(float x, bool wanted)
+	{
+		const bool fast = __builtin_fabsf(x) < 0x1p60f;
+		float q = rcp_core(x, __builtin_amdgcn_rcpf(x));
+		if (wanted && !fast)
+		{
+			RT_HIP_RARE_PATH();
+			q = 1.0f / x;
+		}
+		return q;
+	}
 
 	// ---- the reciprocal square root of normalize(): contract v3 -----------------------------------------------------
 	// v2 defined normalize() through 1.0f / sqrtf(x) and kept BOTH roundings: a quarter-rate v_rsq AND a quarter-rate

@@ -168,7 +168,8 @@ namespace
 			const uint32_t bits = (k << 22) | tid;
 			const float x = __uint_as_float(bits);
 			const bool ok[3] = { same_float(sqrt_rn(x), __builtin_sqrtf(x)),
-								 same_float(rcp_rn(x), 1.0f / x),
+								 // (the plane test's form too, over the arguments its caller may hand it: not below 2^-60, or NaN)
+								 same_float(rcp_rn(x), 1.0f / x) && (__builtin_fabsf(x) < 0x1p-60f || same_float(rcp_rn_not_tiny_where(x, true), 1.0f / x)),
 								 same_float(inv_sqrt_rn(x), inv_sqrt_definition(x)) };
 #pragma unroll
 			for (int f = 0; f < 3; f++)

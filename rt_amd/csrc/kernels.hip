@@ -885,9 +885,15 @@ namespace rt_hip
 #pragma unroll
 							for (int j = 0; j < NP; j++)
 								test_plane(best_plane, st.origin, st.dir, small.geometry[(NS > 0 ? NS : 0) + j], static_cast<uint32_t>(j));
-							uint32_t index;
-							kind = select_hit(best, best_plane, distance, index);
-							small_index = kind == 1u ? best.index : static_cast<uint32_t>(NS) + best_plane.index; // the winner's slot (one select; with one plane its index is a constant)
+							// select_hit() (scan.hpp) on the comparisons' masks: written over sentinel distances it costs three selects and a
+							// divergent block more per query.  `>= 0` is hit_result's `operator bool` (:29-32; false for a NaN distance).
+							const bool nearer = best.t <= best_plane.t;
+							const bool sphere = best.have && best.t >= 0.0f, plane = best_plane.have && best_plane.t >= 0.0f;
+							const bool use_sphere = sphere && (!plane || nearer);
+							const bool use_plane = plane && !use_sphere;
+							distance = use_sphere ? best.t : best_plane.t; // (a miss never reads it)
+							kind = use_sphere ? 1u : (use_plane ? 2u : 0u);
+							small_index = use_sphere ? best.index : static_cast<uint32_t>(NS) + best_plane.index; // the winner's slot (one select; with one plane its index is a constant)
 						}
 						else
 						{

@@ -83,14 +83,21 @@ namespace rt_hip
 			// a select and a second comparison per lane.  "positive, finite, not zero" either way; a NaN fails both.)
 			const float product = num * den;
 			const bool positive = product > 0.0f, finite = product < __builtin_inff();
-			const bool in_reach = crosses && !(positive && finite);
+#ifdef RT_HIP_PLANE_ALWAYS_RECIPROCAL // (A/B build: no vote on "hopeless", every crossing wave takes the reciprocal)
+			(void)positive, (void)finite;
+#else
 			if ((crossing & ~(__builtin_amdgcn_ballot_w64(positive) & __builtin_amdgcn_ballot_w64(finite))) != 0)
+#endif
 			{
 				// (the empty statement keeps hipcc from flattening this wave-uniform branch: everything below is selects,
 				// and it would otherwise run the reciprocal on every trip — it did, measured)
 				asm volatile("; the reciprocal of a plane test: some lane is in reach" ::: "memory");
-				const float t = (-num) * rcp_rn(in_reach ? den : 1.0f);
-				const bool accept = in_reach && !(t < min_hit_dist) && !(best.have && best.t <= t);
+				// Every crossing lane takes the reciprocal, the hopeless ones of a mixed wave too: their t = -num / den comes out
+				// negative (or -0) and fails `t < min_hit_dist` by itself, so the per-lane "in reach" is never needed — only the
+				// wave's vote above.  |den| > approx_zero_epsilon in a crossing lane (or den is NaN): the reciprocal's band has
+				// only its upper end left to check.
+				const float t = (-num) * rcp_rn_not_tiny_where(den, crosses);
+				const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
 				best.t = accept ? t : best.t;
 				best.index = accept ? index : best.index;
 				best.have = best.have || accept;

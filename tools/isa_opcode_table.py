@@ -110,10 +110,14 @@ def print_loop(path, key):
     begin = next(i for i, l in enumerate(lines) if l.startswith("_Z") and key in l and ":" in l)
     end = next(i for i in range(begin, len(lines)) if lines[i].startswith(".Lfunc_end"))
     lines = lines[begin:end]
-    start = next(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
-    # the loop's back edge target may sit a few blocks above the header: take everything from the first block that branches into it
-    stop = next(i for i in range(start, len(lines)) if re.search(r"v_and_b32_e32 v\d+, 63, v0", lines[i]))
-    out, i = [], max(start - 12, 0)
+    header = next(i for i, l in enumerate(lines) if "Loop Header: Depth=1" in l)
+    name = re.match(r"^\.L(BB\d+_\d+):", lines[header - 1] if lines[header].lstrip().startswith(";") and not lines[header].startswith(".L") else lines[header])
+    name = name.group(1) if name else re.match(r"^\.L(BB\d+_\d+):", lines[header]).group(1)
+    inside = [i for i, l in enumerate(lines) if f"Header={name} " in l or i == header]
+    start = min(inside)
+    # the loop ends where the first block behind its last block begins
+    stop = next(i for i in range(max(inside) + 1, len(lines)) if re.match(r"^(\.LBB|; %bb)", lines[i]))
+    out, i = [], max(start - 1, 0)
     while i < stop:
         l = lines[i]
         if "rare path" in l:
