@@ -880,20 +880,31 @@ namespace rt_hip
 						}
 						if (NP > 0)
 						{
-							// test_planes (:36-60) over the plane slots, with its own best candidate; then select(spheres, planes) (:96-102,160)
-							candidate best_plane = { 0.0f, 0u, false };
-#pragma unroll
-							for (int j = 0; j < NP; j++)
-								test_plane(best_plane, st.origin, st.dir, small.geometry[(NS > 0 ? NS : 0) + j], static_cast<uint32_t>(j));
+							// test_planes (:36-60) over the plane slots, with its own best candidate; then select(spheres, planes) (:96-102,160) —
 							// select_hit() (scan.hpp) on the comparisons' masks: written over sentinel distances it costs three selects and a
 							// divergent block more per query.  `>= 0` is hit_result's `operator bool` (:29-32; false for a NaN distance).
-							const bool nearer = best.t <= best_plane.t;
-							const bool sphere = best.have && best.t >= 0.0f, plane = best_plane.have && best_plane.t >= 0.0f;
+							float plane_distance;
+							uint32_t plane_slot = static_cast<uint32_t>(NS);
+							bool plane;
+							if (NP == 1)
+								plane = test_one_plane(st.origin, st.dir, small.geometry[NS > 0 ? NS : 0], plane_distance);
+							else
+							{
+								candidate best_plane = { 0.0f, 0u, false };
+#pragma unroll
+								for (int j = 0; j < NP; j++)
+									test_plane(best_plane, st.origin, st.dir, small.geometry[(NS > 0 ? NS : 0) + j], static_cast<uint32_t>(j));
+								plane = best_plane.have && best_plane.t >= 0.0f;
+								plane_distance = best_plane.t;
+								plane_slot += best_plane.index;
+							}
+							const bool nearer = best.t <= plane_distance;
+							const bool sphere = best.have && best.t >= 0.0f;
 							const bool use_sphere = sphere && (!plane || nearer);
 							const bool use_plane = plane && !use_sphere;
-							distance = use_sphere ? best.t : best_plane.t; // (a miss never reads it)
+							distance = use_sphere ? best.t : plane_distance; // (a miss never reads it)
 							kind = use_sphere ? 1u : (use_plane ? 2u : 0u);
-							small_index = use_sphere ? best.index : static_cast<uint32_t>(NS) + best_plane.index; // the winner's slot (one select; with one plane its index is a constant)
+							small_index = use_sphere ? best.index : plane_slot; // the winner's slot (one select; with one plane its index is a constant)
 						}
 						else
 						{
@@ -1252,7 +1263,10 @@ namespace rt_hip
 							toward = { fma(p.eye_jq1[0], jx, fma(p.eye_jq2[0], jy, st.base_x)), fma(p.eye_jq1[1], jx, fma(p.eye_jq2[1], jy, st.base_y)),
 									   fma(p.eye_jq1[2], jx, fma(p.eye_jq2[2], jy, st.base_z)) };
 							const float ws = fma(p.eye_jw1, jx, fma(p.eye_jw2, jy, st.base_w));
-							const bool plain = p.eye_form == 2u; // (wave-uniform) the host has shown ws in the band and N.w F.w > 0 for the whole frame
+							// (wave-uniform) the host has shown ws in the band and N.w F.w > 0 for the whole frame — every frame of a camera
+							// that looks at its scene; the scalar-register kernels are built for such frames only (choose_kernel), anything
+							// else — near and far points on different sides of w = 0, a w at the band's ends — goes through the resident kernel
+							const bool plain = EYE_ONLY || p.eye_form == 2u;
 							float inv;
 							if (plain)
 								inv = rcp_in_band(ws);
@@ -1578,7 +1592,7 @@ namespace rt_hip
 			return RT_HIP_KERNEL_TILED;
 		// up to 8 primitives: at least one sphere, at most three planes (round 4: neither a plane nor a camera whose w varies
 		// over the frame pushes a scene off this kernel any more)
-		// ... through a camera with an eye (`perspective`: the pinhole or the eye form; the scalar-register kernels are built for those)
+		// ... through a camera with an eye (`perspective`: the pinhole or the plain eye form; the scalar-register kernels are built for those)
 		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && perspective && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
@@ -1761,7 +1775,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.pinhole != 0 || frame.eye_form != 0);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.pinhole != 0 || frame.eye_form == 2u);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes,

@@ -213,7 +213,7 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective /* the frame's camera has an eye: frame_params::pinhole or eye_form */);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective /* the frame's camera is a pinhole or a plain eye-form one: frame_params::pinhole or eye_form == 2 */);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,

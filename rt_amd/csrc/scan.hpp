@@ -61,48 +61,36 @@ namespace rt_hip
 	}
 
 	// One plane of test_planes (:43-52).  `pl` = (normal, d), wave-uniform.
-	// The distance t = -num * (1 / den) takes a correctly rounded reciprocal (a handful of issue slots and a guard) and is only
-	// worth taking for a lane whose plane can still be ACCEPTED.  A lane is hopeless — t < min_hit_dist for certain, and no NaN
-	// can come of it — when num * den is a positive FINITE number (one multiply, one v_cmp_class): then num and den are both
-	// finite, non-zero and of one sign, and -num / den is negative.  Rays that point away from a ground plane — every sky tile's
-	// primary rays, most bounces off the ground — are hopeless wave-wide, and the reciprocal is skipped with one vote.  Anything
-	// else (a zero, an infinity, a NaN, a product that under- or overflows) takes it as before: the results are the same bits
-	// for every input (tests/test_oracle_kat.py::test_plane_lanes_the_kernels_call_hopeless_...).
-	// (The two votes are taken from the comparisons themselves and combined on the scalar unit: a vote on their conjunction is
-	// compiled as a select and a second comparison per lane.)
+	// The distance t = -num * (1 / den) takes a correctly rounded reciprocal: v_rcp_f32 and one residual step, exact for every
+	// |den| in the band 2^-60 .. 2^60.  A lane that crosses the plane has |den| > approx_zero_epsilon (or a NaN), so only the
+	// band's upper end is left to check — one comparison — and lanes that do not cross compute some value nobody reads.
+	// No votes: rounds 4 and 5 skipped the reciprocal for a wave whose lanes were all "hopeless" (num * den positive and finite:
+	// t < 0 for certain) and skipped the test for a wave without a crossing lane; measured against the straight line below, the
+	// votes cost more than they saved on every plane scene (profiles/r05/plane_ab.txt: 2.42 -> 2.41, 2.77 -> 2.745, 2.745 -> 2.69 ms).
 	__device__ __forceinline__ void test_plane(candidate& best, vec3 o, vec3 d, float4 pl, uint32_t index)
 	{
 		const vec3 n = { pl.x, pl.y, pl.z };
 		const float den = dot(n, d);
 		const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
-		const unsigned long long crossing = __builtin_amdgcn_ballot_w64(crosses);
-		if (crossing != 0)
-		{
-			const float num = dot(n, o) + pl.w;
-			// (two comparisons whose votes the scalar unit combines, not one v_cmp_class: hipcc turns a vote on a class test into
-			// a select and a second comparison per lane.  "positive, finite, not zero" either way; a NaN fails both.)
-			const float product = num * den;
-			const bool positive = product > 0.0f, finite = product < __builtin_inff();
-#ifdef RT_HIP_PLANE_ALWAYS_RECIPROCAL // (A/B build: no vote on "hopeless", every crossing wave takes the reciprocal)
-			(void)positive, (void)finite;
-#else
-			if ((crossing & ~(__builtin_amdgcn_ballot_w64(positive) & __builtin_amdgcn_ballot_w64(finite))) != 0)
-#endif
-			{
-				// (the empty statement keeps hipcc from flattening this wave-uniform branch: everything below is selects,
-				// and it would otherwise run the reciprocal on every trip — it did, measured)
-				asm volatile("; the reciprocal of a plane test: some lane is in reach" ::: "memory");
-				// Every crossing lane takes the reciprocal, the hopeless ones of a mixed wave too: their t = -num / den comes out
-				// negative (or -0) and fails `t < min_hit_dist` by itself, so the per-lane "in reach" is never needed — only the
-				// wave's vote above.  |den| > approx_zero_epsilon in a crossing lane (or den is NaN): the reciprocal's band has
-				// only its upper end left to check.
-				const float t = (-num) * rcp_rn_not_tiny_where(den, crosses);
-				const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
-				best.t = accept ? t : best.t;
-				best.index = accept ? index : best.index;
-				best.have = best.have || accept;
-			}
-		}
+		const float num = dot(n, o) + pl.w;
+		const float t = (-num) * rcp_rn_not_tiny_where(den, crosses);
+		const bool accept = crosses && !(t < min_hit_dist) && !(best.have && best.t <= t);
+		best.t = accept ? t : best.t;
+		best.index = accept ? index : best.index;
+		best.have = best.have || accept;
+	}
+
+	// The ONE plane of a scene that has one (rt's scenes with their ground plane), for select_hit_one_plane() below: test_planes'
+	// candidate is accepted <=> crosses && !(t < min_hit_dist), and select() (:96-102) then asks `t >= 0` of it, which a NaN fails
+	// and every other accepted distance passes (min_hit_dist > 0): both are the one ordered comparison t >= min_hit_dist.
+	__device__ __forceinline__ bool test_one_plane(vec3 o, vec3 d, float4 pl, float& t)
+	{
+		const vec3 n = { pl.x, pl.y, pl.z };
+		const float den = dot(n, d);
+		const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
+		const float num = dot(n, o) + pl.w;
+		t = (-num) * rcp_rn_not_tiny_where(den, crosses);
+		return crosses && t >= min_hit_dist;
 	}
 
 	// scan `count` primitives held in LDS (wave-uniform addresses: broadcast reads).  Spheres go four at a time:

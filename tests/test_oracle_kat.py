@@ -674,23 +674,19 @@ def test_normalize_of_unit_vectors_stays_put():
     assert np.max(np.abs(scaled.view(np.int32).astype(np.int64) - v.view(np.int32).astype(np.int64))) <= 1
 
 
-def test_plane_lanes_the_kernels_call_hopeless_are_rejected_by_the_reference_rule():
-    """rt_amd/csrc/scan.hpp test_plane skips the division t = -num / den for lanes it calls hopeless — the binary32 product
-    num * den is a positive finite number — because test_planes (reference mg_ray_tracer.cpp:46-52) would reject them anyway: `hits()` needs
-    t >= 0 and the scan drops t < 0.001.  Checked here on the whole zoo of binary32 classes (zeros of both signs, subnormals,
-    huge values, infinities, NaNs) crossed with itself and on a million random pairs: hopeless => t is not NaN and t < 0.001."""
+def test_one_plane_is_accepted_and_selected_by_one_ordered_comparison():
+    """rt_amd/csrc/scan.hpp test_one_plane (scenes with ONE plane): test_planes accepts the plane's candidate when the ray crosses it
+    and `!(t < 0.001)` (reference mg_ray_tracer.cpp:46-52), select() then asks `distance >= 0` of it (:29-32,96-102) — a NaN distance
+    passes the first and fails the second.  The kernels ask once: crosses and `t >= 0.001`.  Checked on the whole zoo of binary32
+    classes (zeros of both signs, subnormals, huge values, infinities, NaNs) crossed with itself and on a million random pairs."""
     rng = np.random.default_rng(11)
     special = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1e-6, -1e-6, 0.001, -0.001, 1.0, -1.0, 3e38, -3e38, np.inf, -np.inf, np.nan], dtype=np.float32)
     num = np.concatenate([np.repeat(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
     den = np.concatenate([np.tile(special, len(special)), rng.normal(size=1_000_000).astype(np.float32) * np.float32(10.0) ** rng.integers(-30, 30, 1_000_000).astype(np.float32)])
     with np.errstate(all="ignore"):
-        product = num * den  # binary32: may round to 0, overflow to inf, or be NaN — none of which is "hopeless"
-        t = (-num) / den
-    hopeless = (product > 0) & np.isfinite(product)
-    assert hopeless.sum() > 400_000
-    assert not np.isnan(t[hopeless]).any()
-    assert (t[hopeless] < np.float32(0.001)).all()
-    # and the lanes that are NOT hopeless include every lane the reference would accept
+        t = ((-num) * (np.float32(1.0) / den)).astype(np.float32)  # contract v4: the rounded reciprocal, then one product
     crosses = ~(np.abs(den) <= np.float32(1e-6))
     accepted = crosses & ~(t < np.float32(0.001))  # (a NaN distance is "accepted" by the negated comparison, as in the reference)
-    assert not (accepted & hopeless).any()
+    selected = accepted & (t >= 0)
+    assert np.isnan(t[accepted]).any() and selected.sum() > 100_000  # the zoo does hold the cases the two rules differ on
+    assert np.array_equal(selected, crosses & (t >= np.float32(0.001)))
