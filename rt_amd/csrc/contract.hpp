@@ -291,9 +291,14 @@ namespace rt_hip
 	{
 		uint32_t function_key, stride;
 	};
+	__device__ __forceinline__ uint32_t step_word_at(uint32_t counter, stream_keys keys);
 	__device__ __forceinline__ uint32_t next_step_word(uint32_t& counter, stream_keys keys)
 	{
 		counter += keys.stride;
+		return step_word_at(counter, keys);
+	}
+	__device__ __forceinline__ uint32_t step_word_at(uint32_t counter, stream_keys keys)
+	{
 		uint32_t x = counter;
 		x ^= x >> 16;
 		x = x * 0x7feb352du + keys.function_key;

@@ -1123,9 +1123,17 @@ namespace rt_hip
 					// random.hpp:57-66: the third word follows below) or random<float>(), a restarting lane's random<vec2>() (the
 					// pixel jitter, :189).  As numerators k of u = k * 2^-24: the scaling is folded into the jitter's constants and
 					// cancels in the unit vector.
-					uint32_t counter = st.counter;
-					const uint32_t counter_at_start = counter;
-					uint32_t word = next_step_word(counter, st.keys);
+					// (The step advances EVERY lane's counter in place — a free or retired lane's too, whose counter nobody reads before
+					// start_item sets it.  Nothing below needs the value it had: "the stream stood at 0" reads "it now stands at one
+					// stride".  Advanced in a copy and written back by the lanes that shade or restart, it cost a register move per trip.)
+#ifdef RT_HIP_FAST_BUILD
+					uint32_t word = next_step_word(st.counter, st.keys);
+#else
+					// (the addition written out with its result tied to its operand's register: hipcc otherwise adds into a second
+					// register and moves the sum back at the end of the trip)
+					asm("v_add_u32 %0, %0, %1" : "+v"(st.counter) : "v"(st.keys.stride));
+					uint32_t word = step_word_at(st.counter, st.keys);
+#endif
 					uint32_t word_a = word * step_mul_a, word_b = word * step_mul_b;
 					float d0 = step_numerator(word_a);
 					float d1 = step_numerator(word_b);
@@ -1165,7 +1173,6 @@ namespace rt_hip
 							const double x5 = (x2 * x2) * x;
 							reflect_prob = static_cast<float>(static_cast<double>(r0) + static_cast<double>(1.0f - r0) * x5);
 						}
-						st.counter = counter; // random<float>(): one step, its first draw
 						toward = (d0 * random_scale < reflect_prob) ? reflected : refracted;
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z };
 						const bool dead = mode == lane_trace; // no bounce left: the next trace() call would return {} at :157-158
@@ -1179,7 +1186,7 @@ namespace rt_hip
 						uint32_t word_c = word * step_mul_c;
 						while (((word_a | word_b | word_c) >> 8) == 0u) // `if (p == zero) continue` (random.hpp:61-62): the next step
 						{
-							word = next_step_word(counter, st.keys);
+							word = next_step_word(st.counter, st.keys);
 							word_a = word * step_mul_a, word_b = word * step_mul_b, word_c = word * step_mul_c;
 							d0 = step_numerator(word_a);
 							d1 = step_numerator(word_b);
@@ -1216,7 +1223,6 @@ namespace rt_hip
 						}
 						st.throughput = st.throughput * vec3{ shading.x, shading.y, shading.z }; // attenuation * trace(...) (:171)
 						toward = scatter;
-						st.counter = counter;
 						// absorbed, or the next trace() call would return {} at :157-158 (`if (!(max_bounces--))`: the count is kept
 						// as the bounces still allowed after the segment in flight, and only a bounce touches it)
 						const bool dead = absorbed || mode == lane_trace;
@@ -1235,13 +1241,14 @@ namespace rt_hip
 						// sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing (:189).  Its window is the one
 						// that starts at stream position 0.  One restart in spp is such a sample, and a wave meets them all in its first
 						// trips: a vote keeps the two selects and the rewind out of every other trip.
-						if (__builtin_amdgcn_ballot_w64(counter_at_start == 0u) != 0)
+						const bool at_sample_0 = st.counter == st.keys.stride;
+						if (__builtin_amdgcn_ballot_w64(at_sample_0) != 0)
 						{
 							asm volatile("; restart: some lane is at its pixel's sample 0" ::: "memory");
-							if (counter_at_start == 0u)
+							if (at_sample_0)
 							{
 								jx = jy = 0x1.0p23f;
-								counter = counter_at_start;
+								st.counter = 0u; // (the sample draws nothing: back to the window's start)
 							}
 						}
 						if (PINHOLE_ONLY || (!EYE_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
@@ -1308,7 +1315,6 @@ namespace rt_hip
 						}
 						toward2 = dot(toward, toward);
 						st.throughput = { 1.0f, 1.0f, 1.0f };
-						st.counter = counter;
 						mode = lane_trace + (p.max_bounces - 1u); // tracing, max_bounces - 1 bounces to go after the primary segment
 					}
 					if (shade || restart)
@@ -1593,7 +1599,8 @@ namespace rt_hip
 		// up to 8 primitives: at least one sphere, at most three planes (round 4: neither a plane nor a camera whose w varies
 		// over the frame pushes a scene off this kernel any more)
 		// ... through a camera with an eye (`perspective`: the pinhole or the plain eye form; the scalar-register kernels are built for those)
-		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && perspective && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres)
+		// ... and planes whose normals are of ordinary size (device_scene::planes_tame)
+		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && perspective && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres && (scene.n_planes == 0 || scene.planes_tame))
 			return RT_HIP_KERNEL_SMALL;
 		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
 		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against

@@ -42,6 +42,10 @@ namespace rt_hip
 		uint32_t n_boxes;
 		const float4* box_bounds;
 		const float4* material_albedo;
+		// every plane normal is finite with components of at most 2^40 in magnitude (scene.hip; any scene rt's loader makes: it
+		// normalises them).  A ray's direction is normalised, so n . d is then NaN, infinite (a degenerate direction) or below 2^60:
+		// what lets the scalar-register kernels take a lone plane's 1 / (n . d) without a guard (scan.hpp, test_one_plane)
+		uint32_t planes_tame;
 	};
 
 	enum : uint32_t

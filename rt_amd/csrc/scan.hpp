@@ -80,16 +80,21 @@ namespace rt_hip
 		best.have = best.have || accept;
 	}
 
-	// The ONE plane of a scene that has one (rt's scenes with their ground plane), for select_hit_one_plane() below: test_planes'
-	// candidate is accepted <=> crosses && !(t < min_hit_dist), and select() (:96-102) then asks `t >= 0` of it, which a NaN fails
-	// and every other accepted distance passes (min_hit_dist > 0): both are the one ordered comparison t >= min_hit_dist.
+	// The ONE plane of a scene that has one (rt's scenes with their ground plane), for the scalar-register kernels.
+	// test_planes' candidate is accepted <=> crosses && !(t < min_hit_dist), and select() (:96-102) then asks `t >= 0` of it, which
+	// a NaN fails and every other accepted distance passes (min_hit_dist > 0): both are the one ORDERED comparison t >= min_hit_dist.
+	// And because nothing but that comparison reads t in a lane that is not selected, the reciprocal needs no guard here: the
+	// caller's scene has tame normals (device_scene::planes_tame) and a ray's direction is normalised, so den = n . d is below 2^60,
+	// infinite or NaN; a crossing lane has |den| > approx_zero_epsilon: inside the band rcp_in_band() is the rounded quotient, and
+	// for an infinite or NaN den both it (NaN) and the quotient (0, NaN) make a t that fails the comparison
+	// (tests/test_oracle_kat.py::test_one_plane_is_accepted_and_selected_by_one_ordered_comparison).
 	__device__ __forceinline__ bool test_one_plane(vec3 o, vec3 d, float4 pl, float& t)
 	{
 		const vec3 n = { pl.x, pl.y, pl.z };
 		const float den = dot(n, d);
 		const bool crosses = !(__builtin_fabsf(den) <= approx_zero_epsilon);
 		const float num = dot(n, o) + pl.w;
-		t = (-num) * rcp_rn_not_tiny_where(den, crosses);
+		t = (-num) * rcp_in_band(den);
 		return crosses && t >= min_hit_dist;
 	}
 

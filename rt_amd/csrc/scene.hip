@@ -7,6 +7,7 @@
 #include "internal.hpp"
 
 #include <algorithm>
+#include <cmath>
 #include <exception>
 
 using namespace rt_hip;
@@ -317,6 +318,11 @@ namespace rt_hip
 			d.n_boxes = s.n_boxes;
 			d.box_bounds = reinterpret_cast<const float4*>(base + L.box_bounds);
 			d.material_albedo = reinterpret_cast<const float4*>(base + L.albedo);
+			d.planes_tame = 1u;
+			for (uint32_t k = 0; k < s.n_planes; k++)
+				for (const float n : { s.plane_normal_x[k], s.plane_normal_y[k], s.plane_normal_z[k] })
+					if (!(std::fabs(n) <= 0x1p40f)) // (a NaN fails too)
+						d.planes_tame = 0u;
 		}
 		ctx->samples_per_pixel = s.samples_per_pixel;
 		ctx->max_bounces = s.max_bounces;

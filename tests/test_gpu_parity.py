@@ -241,6 +241,26 @@ def test_the_reference_scenes_with_their_ground_plane_stay_on_the_scalar_registe
         assert stats["segments"] == want_stats["segments"] and stats["plane_tests"] == want_stats["segments"]
 
 
+def test_a_plane_whose_normal_is_not_of_ordinary_size_leaves_the_scalar_register_kernel(tracer):
+    """The scalar-register kernels take a lone plane's 1 / (n . d) without a guard (scan.hpp test_one_plane), which rests on n . d
+    staying below 2^60: plane normals with components of at most 2^40 (device_scene::planes_tame; rt's loader normalises them).
+    The C ABI takes any columns: a normal of length 3e12 — or an infinite one — sends the scene to the LDS-resident kernel, whose
+    plane test is guarded, and the frame stays bit-exact; the same plane scaled to unit length takes the scalar-register kernel."""
+    rng = np.random.default_rng(77)
+    materials = [(0, 0.7, 0.6, 0.5, 1.0, 0.0, 1.0), (1, 0.9, 0.9, 0.9, 1.0, 0.1, 1.0)]
+    spheres = [(rng.uniform(-2, 2), rng.uniform(0.3, 1.5), rng.uniform(-6, -2), rng.uniform(0.4, 1.0), int(rng.integers(0, 2))) for _ in range(3)]
+    ivp = rt_amd.Scene.parse("").set_camera((0.0, 1.0, 3.0), (0.0, -0.2, -1.0)).describe(96, 54).inverse_view_projection[:]
+    for scale, expected in ((1.0, "small"), (3.0e12, "resident"), (float("inf"), "resident")):
+        planes = [(0.0, scale, 0.0, 0.25 * min(scale, 3.0e12), 1)]
+        pod = rt_amd.scene_from_arrays(spheres, planes, materials, samples_per_pixel=12, max_bounces=6, inverse_view_projection=ivp)
+        got_rgba, got_rgb, stats = tracer.render(pod, 96, 54, seed=9, want_rgb=True)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, 96, 54, seed=9)
+        assert stats["kernel"] == expected
+        same = (got_rgb.view(np.uint32) == want_rgb.view(np.uint32)) | (np.isnan(got_rgb) & np.isnan(want_rgb))
+        assert same.all() and np.array_equal(got_rgba, want_rgba), f"normal scaled by {scale}"
+        assert stats["segments"] == want_stats["segments"]
+
+
 @pytest.mark.parametrize("n_spheres,n_planes", [(s, p) for p in (1, 2, 3) for s in range(1, 9 - p)] + [(0, 1), (6, 3), (1, 4)])
 def test_every_sphere_and_plane_count_of_the_scalar_register_kernel(tracer, n_spheres, n_planes):
     """One random scene per (spheres, planes) combination the scalar-register kernel is built for — 1..7 spheres followed by

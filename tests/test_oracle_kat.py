@@ -690,3 +690,13 @@ def test_one_plane_is_accepted_and_selected_by_one_ordered_comparison():
     selected = accepted & (t >= 0)
     assert np.isnan(t[accepted]).any() and selected.sum() > 100_000  # the zoo does hold the cases the two rules differ on
     assert np.array_equal(selected, crosses & (t >= np.float32(0.001)))
+    # the scalar-register kernels take the reciprocal UNGUARDED (rcp_in_band): v_rcp_f32 and one residual step — the rounded
+    # quotient inside the band, NaN for an infinite den (0 * inf in the residual) where the quotient is 0.  Their dens are below
+    # 2^60, infinite or NaN (device_scene::planes_tame), and neither a NaN nor a zero times anything passes the comparison.
+    tame = ~(np.isfinite(den) & (np.abs(den) >= np.float32(2.0**60)))
+    with np.errstate(all="ignore"):
+        unguarded = np.where(np.isinf(den), np.float32(np.nan), np.float32(1.0) / den).astype(np.float32)
+        t_unguarded = ((-num) * unguarded).astype(np.float32)
+    assert np.isinf(den[crosses & tame]).any()
+    assert np.array_equal(selected[tame], (crosses & (t_unguarded >= np.float32(0.001)))[tame])
+    assert np.array_equal(t[selected & tame].view(np.uint32), t_unguarded[selected & tame].view(np.uint32))

@@ -18,7 +18,7 @@ NAMES = ["trip", "query: probes", "sqrt half of a sphere", "hit: lookups + norma
 scene, w, h, spp = (sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else ("basic", 1920, 1080, 256)
 t = rt_amd.HipRayTracer(0)
 lib = capi.hip_lib()
-pod = rt_amd.Scene.named(scene).set_sampling(spp).describe(w, h)
+pod = (rt_amd.Scene.load(scene) if scene.endswith(".toml") else rt_amd.Scene.named(scene)).set_sampling(spp).describe(w, h)
 t.upload(pod)
 frame = torch.empty((h, w), dtype=torch.int32, device="cuda:0")
 t.render_device(w, h, frame.data_ptr(), seed=1, stream=torch.cuda.current_stream().cuda_stream)
