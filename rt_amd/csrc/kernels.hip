@@ -683,8 +683,13 @@ namespace rt_hip
 			constexpr bool INDEXED = HALF || ROLLING;
 			const auto next_sample = [&]() -> bool
 			{
+#ifdef RT_HIP_FAST_BUILD
 				st.window += st.keys.stride << draws_per_sample_log2;
-				st.counter = st.window;
+#else
+				// (written out with its result tied to its operand's register: hipcc otherwise forms the sum in the counter's register
+				// and carries the window through two more moves to the end of the query)
+				asm("v_lshl_add_u32 %0, %1, %2, %0" : "+v"(st.window) : "v"(st.keys.stride), "n"(draws_per_sample_log2));
+#endif
 				if (INDEXED)
 					return ++st.sample < st.sample_end;
 				return st.window != st.window_end;
@@ -1017,7 +1022,7 @@ namespace rt_hip
 					const uint32_t first = chunk * item_samples, end = min(first + item_samples, p.samples_per_pixel);
 					st.sample = first;
 					st.sample_end = end;
-					st.window = st.counter = sample_counter(st.keys.stride, first);
+					st.window = sample_counter(st.keys.stride, first);
 					st.window_end = sample_counter(st.keys.stride, end);
 					RT_HIP_BECOME(lane_restart);
 				};
@@ -1126,6 +1131,10 @@ namespace rt_hip
 					// (The step advances EVERY lane's counter in place — a free or retired lane's too, whose counter nobody reads before
 					// start_item sets it.  Nothing below needs the value it had: "the stream stood at 0" reads "it now stands at one
 					// stride".  Advanced in a copy and written back by the lanes that shade or restart, it cost a register move per trip.)
+					// A restarting lane draws from the start of its sample's window, a scattering lane goes on where it stands: one select.
+					// (Rounds 4-5 had next_sample() copy the window into the counter instead — a move per miss, and three more per trip
+					// that carried the two versions of the counter through the hit / miss join.)
+					st.counter = restart ? st.window : st.counter;
 #ifdef RT_HIP_FAST_BUILD
 					uint32_t word = next_step_word(st.counter, st.keys);
 #else
@@ -1241,7 +1250,7 @@ namespace rt_hip
 						// sample 0 goes through the pixel centre (0.5 = 2^23 * 2^-24) and draws nothing (:189).  Its window is the one
 						// that starts at stream position 0.  One restart in spp is such a sample, and a wave meets them all in its first
 						// trips: a vote keeps the two selects and the rewind out of every other trip.
-						const bool at_sample_0 = st.counter == st.keys.stride;
+						const bool at_sample_0 = st.window == 0u;
 						if (__builtin_amdgcn_ballot_w64(at_sample_0) != 0)
 						{
 							asm volatile("; restart: some lane is at its pixel's sample 0" ::: "memory");

@@ -386,9 +386,33 @@ def test_the_back_buffer_ends_up_on_the_numa_node_of_the_gpu_that_stores_into_it
 
     nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
     width, height = 1920, 136
+
+    def node_takes_pages(node, nbytes):
+        """The module asks with MPOL_PREFERRED (best effort: a node that is short of free memory, or outside the job's cpuset.mems,
+        leaves the pages where they fall — that happened on one box of round 5).  The same request on a buffer of this test's own tells
+        whether THIS host honours it for this node right now; where it does not, there is nothing to hold the module to."""
+        import ctypes
+
+        libc = ctypes.CDLL(None, use_errno=True)
+        probe = np.zeros(nbytes // 4, dtype=np.uint32)  # calloc: untouched, like the frame below
+        page = os.sysconf("SC_PAGESIZE")
+        begin = (probe.ctypes.data + page - 1) // page * page
+        end = (probe.ctypes.data + probe.nbytes) // page * page
+        mask = (ctypes.c_ulong * 16)()
+        mask[node // 64] = 1 << (node % 64)
+        if libc.syscall(237, ctypes.c_void_p(begin), ctypes.c_ulong(end - begin), 1, mask, ctypes.c_ulong(1025), 2) != 0:  # SYS_mbind, MPOL_PREFERRED, MPOL_MF_MOVE
+            return False
+        probe[:] = 1
+        where = page_nodes(probe)
+        return where is not None and set(where) == {node}
+
     pod = rt_amd.Scene.named("basic").set_sampling(1).describe(width, height)
     want, _, _ = oracle.render(pod, width, height, seed=1, want_rgb=False)
+    held = 0
     for node in nodes:
+        if not node_takes_pages(node, 4 * width * height):
+            continue
+        held += 1
         monkeypatch.setenv("RT_HIP_NUMA_NODE", str(node))
         for make in (lambda: rt_amd.HipRayTracer(0), lambda: rt_amd.HipRayTracer(devices=[0, 0], peer_copy=True, direct_frame=True)):
             t = make()
@@ -396,5 +420,7 @@ def test_the_back_buffer_ends_up_on_the_numa_node_of_the_gpu_that_stores_into_it
             got, _, _ = t.render(pod, width, height, seed=1, flags=capi.RT_HIP_FLAG_PERSISTENT_FRAME, out=frame)
             assert np.array_equal(got, want)
             placed = page_nodes(frame)
-            assert placed is not None and set(placed) == {node}, (node, sorted(set(placed)))
             t.close()
+            assert placed is not None and set(placed) == {node}, (node, sorted(set(placed)))
+    if not held:
+        pytest.skip("no NUMA node of this host takes preferred pages right now")
