@@ -882,7 +882,7 @@ def test_noise_statistics_at_1080p_match_independent_generators(tracer):
     scene = rt_amd.Scene.named("basic")
     def checked(img, name):
         """The radiance of this scene is <= 1.  In round 3 ONE run of this test found float64 garbage in `truth` — bytes of packed
-        RGBA8 pixels in an array no render writes to (DESIGN.md §9 has the analysis; the module has handed the HIP runtime no
+        RGBA8 pixels in an array no render writes to (HISTORY.md §9 has the analysis; the module has handed the HIP runtime no
         caller memory since).  No second chance: the first wild value fails the test and says where it is."""
         wild = np.argwhere(~(np.abs(img) < 4.0).all(axis=-1))
         assert len(wild) == 0, (f"{name}: {len(wild)} pixels outside [0, 4); first at (y, x) = {wild[:8].tolist()}, values {img[tuple(wild[0])]}, "

@@ -1,7 +1,7 @@
 """A SECOND restatement of the path, independent of oracle/cpu_ref.cpp: numpy, binary64, vectorised over all samples of a frame,
 written from the reference's text — worker lambda and trace (src/renderers/mg_ray_tracer.cpp:155-201), test_planes / test_spheres
 / select (:36-102), lambert_scatter / metal_scatter (:110-140), screen_to_world (src/camera.hpp:42-48) — and from the stream
-contract (DESIGN.md §3.6; the numpy generator of tests/test_oracle_kat.py, itself independent of the oracle's C++).
+contract (DESIGN.md §3.3; the numpy generator of tests/test_oracle_kat.py, itself independent of the oracle's C++).
 
 The oracle is unpinned (the reference has no tests and cannot be built here): the only tie between it and the reference is
 one reading of the source.  This file is a second coding of that reading in another language, another precision and another

@@ -85,7 +85,7 @@ def test_primary_rays_match_pinhole_model(size):
         o, d, form = oracle_primary_ray_at(pod, width, height, px, py, want_form=True)
         assert form == "pinhole"  # rt's camera, axis-aligned: the per-pixel base form
         want = analytic_primary_direction(px, py, width, height)
-        # float32 inverse view-projection with near 0.01 / far 1000: ~1e-5 rad of direction error (DESIGN.md §3.3)
+        # float32 inverse view-projection with near 0.01 / far 1000: ~1e-5 rad of direction error (DESIGN.md §3.4)
         assert np.allclose(d, want, atol=5e-5), (px, py, d, want)
         # origin lies on the same eye ray, close to the eye (near plane 0.01)
         off = o.astype(np.float64) - eye
