@@ -32,14 +32,15 @@ def test_issue_by_class_prices_every_instruction_once():
     cycles = 600 * cost["fma_f32"] + 20 * cost["trans_f32"] + 10 * cost["cvt"] + 150 * cost["int32"] + 20 * cost["int64"] + 200 * cost["other"]
     assert abs(got["issue_time_ms"] - cycles / (1024 * bench.SHADER_CLOCK_HZ) * 1e3) < 1e-4  # (the line rounds to 0.1 us)
     assert bench.issue_by_class({"SQ_INSTS_VALU": 1000.0}, 1.0, 1024) is None  # an entry without the class passes: no figure
-    # the committed figures: every entry that has the class counters prices to less than its kernel's own time
+    # the committed figures: every entry that has the class counters prices to no more than its kernel's own time — within the 2-3 %
+    # the per-class prices are measured to (profiles/r04/valu_issue_costs.txt): the 64-sphere scan of round 5 prices to 1.008 of its time
     table = json.loads((ROOT / "profiles" / "pmc_counters.json").read_text())
     priced = 0
     for key, rec in table.items():
         by_class = bench.issue_by_class(rec["counters_per_launch"], rec["kernel_ms_traced_mean_of_timed_steps"], 1024)
         if by_class:
             priced += 1
-            assert 0.5 < by_class["frac_of_kernel_time"] <= 1.0, (key, by_class)
+            assert 0.5 < by_class["frac_of_kernel_time"] <= 1.03, (key, by_class)
     assert priced >= 2
 
 
