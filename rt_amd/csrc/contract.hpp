@@ -217,7 +217,7 @@ namespace rt_hip
 	// muu::ray::at
 	__device__ __forceinline__ vec3 ray_at(vec3 o, vec3 d, float t) { return { fma(d.x, t, o.x), fma(d.y, t, o.y), fma(d.z, t, o.z) }; }
 
-	// ---- random streams (replaces src/random.cpp:9-26; see DESIGN.md §3.6) ------------------------------------
+	// ---- random streams (replaces src/random.cpp:9-26; see DESIGN.md §3.3) ------------------------------------
 	// Contract v2: every pixel of a frame draws through its OWN keyed hash function, evaluated along its OWN arithmetic
 	// progression of counters — 64 bits of key per (frame, pixel), as the reference's generators are independent of one
 	// another (src/random.cpp:9-13):

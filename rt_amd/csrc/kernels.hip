@@ -199,11 +199,7 @@ namespace rt_hip
 			return true;
 		}
 
-#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE
-		constexpr uint32_t small_table_float4s = 2u * scalar_max_spheres + scalar_max_spheres / 4u;
-#else
 		constexpr uint32_t small_table_float4s = 2u * scalar_max_spheres; // LDS tables of the scalar-register kernels: geometry, shading
-#endif
 
 		// everything a lane carries between loop trips
 		struct lane_state
@@ -328,7 +324,7 @@ namespace rt_hip
 		//   Round 3 wrote a slot as an 8-byte and a 4-byte agent-scope atomic store and read it back the same way: two memory
 		//   requests each way per sample, tallied by the counters at 32 bytes apiece (config 5: WRITE_SIZE 8.9 GB for 2.1 GB of
 		//   payload).  hipcc has no 16-byte atomic, so the single dwordx4 access is written out
-		//   (RT_HIP_SPLIT_PUBLISH=1 builds the old form, for the A/B).
+		//   (the A/B against the old form: profiles/r04/ab_publish_16_bytes.txt).
 		// THE HAND-OVER PROTOCOL (publish -> count the arrival -> the last arrival reads), as the hardware executes it:
 		//   1. the producer's stores are write-through (sc1): when `s_waitcnt vmcnt(0)` lets the wave go on, they have been
 		//      acknowledged by the memory side (gfx950 counts stores in vmcnt and acknowledges a write-through store when it
@@ -349,11 +345,6 @@ namespace rt_hip
 
 		__device__ __forceinline__ void publish_sum(unsigned long long* slot, vec3 sum)
 		{
-#ifdef RT_HIP_SPLIT_PUBLISH
-			const unsigned long long xy = (static_cast<unsigned long long>(__float_as_uint(sum.y)) << 32) | __float_as_uint(sum.x);
-			__hip_atomic_store(slot, xy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			__hip_atomic_store(reinterpret_cast<uint32_t*>(slot + 1), __float_as_uint(sum.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
 			const v4f value = { sum.x, sum.y, sum.z, 0.0f };
 			// The two wait states behind the store are part of it: a VMEM store of more than 64 bits reads its data registers
 			// after issue, and a vector instruction that overwrites them within two wait states corrupts the stored value
@@ -361,28 +352,16 @@ namespace rt_hip
 			// hard way: the sm kernels' next instruction recycled the value's upper half for an address, and z arrived as a
 			// pointer's low word (profiles/r04/case0_bisect.txt).
 			asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(slot), "v"(value) : "memory");
-#endif
 		}
 		__device__ __forceinline__ vec3 read_sum(unsigned long long* slot)
 		{
-#ifdef RT_HIP_SPLIT_PUBLISH
-			const unsigned long long xy = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const uint32_t z = __hip_atomic_load(reinterpret_cast<uint32_t*>(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			return { __uint_as_float(static_cast<uint32_t>(xy)), __uint_as_float(static_cast<uint32_t>(xy >> 32)), __uint_as_float(z) };
-#else
 			v4f value;
 			asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(value) : "v"(slot) : "memory");
 			return { value.x, value.y, value.z };
-#endif
 		}
 		// eight consecutive slots, the loads in flight together
 		__device__ __forceinline__ void read_sums8(unsigned long long* first, vec3 (&out)[8])
 		{
-#ifdef RT_HIP_SPLIT_PUBLISH
-#pragma unroll
-			for (uint32_t k = 0; k < 8u; k++)
-				out[k] = read_sum(first + 2u * k);
-#else
 			v4f v0, v1, v2, v3, v4, v5, v6, v7;
 			asm volatile("global_load_dwordx4 %0, %8, off sc1\n\t"
 						 "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
@@ -398,7 +377,6 @@ namespace rt_hip
 						 : "memory");
 			out[0] = { v0.x, v0.y, v0.z }, out[1] = { v1.x, v1.y, v1.z }, out[2] = { v2.x, v2.y, v2.z }, out[3] = { v3.x, v3.y, v3.z };
 			out[4] = { v4.x, v4.y, v4.z }, out[5] = { v5.x, v5.y, v5.z }, out[6] = { v6.x, v6.y, v6.z }, out[7] = { v7.x, v7.y, v7.z };
-#endif
 		}
 
 		// the arrival of an item at its pixel's counter, and what the lane that brings the LAST item does before it reads
@@ -467,9 +445,6 @@ namespace rt_hip
 						// scalar registers — the scatter function: ONE 16-byte read for both)
 						lds_geometry[i] = make_float4(small.geometry[i].x, small.geometry[i].y, small.geometry[i].z, __uint_as_float(small.scatter[i]));
 						lds_shading[i] = small.shading[i];
-#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE
-						reinterpret_cast<uint32_t*>(lds + 2 * scalar_max_spheres)[i] = small.scatter[i];
-#endif
 					}
 				}
 			}
@@ -963,11 +938,7 @@ namespace rt_hip
 							RT_HIP_REGION(3); // hit: lookups + normal
 							const float4 g = lds_geometry[small_index];
 							shading = lds_shading[small_index];
-#ifdef RT_HIP_SCATTER_FROM_SHADING_TABLE // (A/B build, profiles/r05: the scatter function as a word of its own behind the shading table)
-							scatter_kind = reinterpret_cast<const uint32_t*>(lds + 2 * scalar_max_spheres)[small_index];
-#else
 							scatter_kind = __float_as_uint(g.w);
-#endif
 							if (NP > 0 && kind == 2u)
 								normal = { g.x, g.y, g.z }; // the plane's normal as it is, not flipped toward the ray (:58)
 							else
