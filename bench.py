@@ -793,6 +793,8 @@ def form_main(args) -> None:
             "drop_in_breakdown": dict({"kernel_ms": round(kernels[0], 4), "wall_ms": round(elapsed / args.steps * 1e3, 4)}, **{k: phases[k] for k in PHASE_KEYS if k in phases}),
             "rccl": {"ranks": infos[0]["ranks"], "devices": [i["device"] for i in infos], "rank_of_process": [i["rank"] for i in infos], "transport": infos[0]["transport"], "source": rccl_source},
         }
+        if rank == 0:  # the frame N ranks have just assembled, against the oracle's digest of the whole frame: the same bits for every N
+            extras.update(frame_verdict(np.asarray(back_buffer), oracle_frame_digest(args.scene, args.width, args.height, args.spp, args.max_bounces, args.seed, False)))
         return finish("ok", elapsed=elapsed, kernels=kernels, member0=tracer.member_stats(0), transport_text=FORM_TEXT[form], extras=extras, frames_in_flight=1)  # (member 0 = rank 0's share: the launch the roofline prices)
     except rt_amd.RtHipError as e:  # a collective renderer reports a broken frame on every rank alike
         finish(f"failed: {e}")
