@@ -433,7 +433,10 @@ namespace rt_hip
 			float4* const lds_geometry = lds;
 			float4* const lds_shading = lds + scalar_max_spheres;
 			constexpr bool RESIDENT = NS == 0; // all primitives in LDS
-			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (RESIDENT ? s.n_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
+			// [NS == 0] from resident_scalar_scan_from spheres on the sphere scan reads the table in memory (scalar loads): only the planes are staged
+			const bool spheres_in_lds = RESIDENT && s.n_spheres < resident_scalar_scan_from;
+			const uint32_t lds_spheres = spheres_in_lds ? s.n_spheres : 0u;
+			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (RESIDENT ? lds_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
 			{
 				if (threadIdx.x == 0)
@@ -450,8 +453,8 @@ namespace rt_hip
 			}
 			else if (RESIDENT)
 			{
-				for (uint32_t i = threadIdx.x; i < s.n_spheres + s.n_planes; i += block_threads)
-					lds[i] = s.primitive_geometry[i];
+				for (uint32_t i = threadIdx.x; i < lds_spheres + s.n_planes; i += block_threads)
+					lds[i] = s.primitive_geometry[(s.n_spheres - lds_spheres) + i];
 			}
 			__syncthreads();
 
@@ -900,7 +903,7 @@ namespace rt_hip
 						candidate spheres = { 0.0f, 0u, false };
 						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
 						const float4* const primitives = RESIDENT ? lds : geometry;
-						scan_lds<false>(planes, st.origin, st.dir, primitives + s.n_spheres, s.n_planes, 0);
+						scan_lds<false>(planes, st.origin, st.dir, RESIDENT ? lds + lds_spheres : geometry + s.n_spheres, s.n_planes, 0);
 						if (NS == -2)
 						{
 							if (scanned_together)
@@ -1569,7 +1572,7 @@ namespace rt_hip
 	}
 
 #ifndef RT_HIP_FAST_BUILD
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective)
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective, uint64_t pixels)
 	{
 		const uint32_t primitives = scene.n_spheres + scene.n_planes;
 		if (flags & RT_HIP_FLAG_FORCE_STREAMED)
@@ -1582,10 +1585,13 @@ namespace rt_hip
 		// ... and planes whose normals are of ordinary size (device_scene::planes_tame)
 		if (!(flags & RT_HIP_FLAG_FORCE_RESIDENT) && perspective && scene.n_spheres >= 1 && scene.n_planes <= scalar_max_planes && primitives <= scalar_max_spheres && (scene.n_planes == 0 || scene.planes_tame))
 			return RT_HIP_KERNEL_SMALL;
-		// The LDS-resident kernel (one tile per wave) up to about 700 primitives, or up to its capacity when forced; beyond
-		// that a trip is a scan and the rolling hand-out of the big-scene kernels wins (1 024 spheres x 64 spp: 47.7 against
-		// 50.9 ms; 512: 26.0 against 25.0 — profiles/r03/midsize_kernels.txt).
-		if (primitives <= resident_max_primitives && ((flags & RT_HIP_FLAG_FORCE_RESIDENT) || primitives <= streamed_from_primitives))
+		// The LDS-resident kernel (one tile per wave) up to streamed_from_primitives (kernels.hpp has the measurements), or whatever
+		// its LDS can hold when forced; beyond that a trip is a long scan and the rolling hand-out of the big-scene kernels wins.
+		const uint32_t staged = (scene.n_spheres < resident_scalar_scan_from ? scene.n_spheres : 0u) + scene.n_planes; // what the resident kernel keeps in LDS
+		// (Scenes beyond its LDS capacity only in frames that fill the device — 4M samples, 64 for every lane it holds: in a small
+		// frame of a big scene every wave is a sparse one, and the streamed kernel scans those with all 64 lanes per ray.)
+		const bool fits = primitives <= resident_max_primitives || (primitives <= streamed_from_primitives && pixels * samples_per_pixel >= (1ull << 22));
+		if (staged <= resident_max_primitives && ((flags & RT_HIP_FLAG_FORCE_RESIDENT) || fits))
 			return RT_HIP_KERNEL_RESIDENT;
 		// Big scenes: the scalar-streamed kernel (no staging, no barriers).  Rounds 1-2 chose the LDS-tiled kernel below
 		// 32 samples per pixel, where it was 2 % ahead; since the group prefetch, the cooperative scan of sparse waves and
@@ -1762,7 +1768,7 @@ namespace rt_hip
 	{
 		if (!frame.width || !frame.local_rows)
 			return RT_HIP_KERNEL_NONE;
-		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.pinhole != 0 || frame.eye_form == 2u);
+		const uint32_t variant = choose_kernel(scene, flags, frame.samples_per_pixel, frame.pinhole != 0 || frame.eye_form == 2u, static_cast<uint64_t>(frame.width) * frame.local_rows);
 		const bool sm = (flags & RT_HIP_FLAG_SM_MATERIALS) != 0;
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		const queue_params queue = choose_queue(frame.samples_per_pixel, frame.width, frame.local_rows, big_scene, (flags & launch_flag_host_frame) != 0u, half_chunk_choice(flags), scene.n_spheres + scene.n_planes,
@@ -1806,7 +1812,7 @@ namespace rt_hip
 		}
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
-			const size_t lds_bytes = static_cast<size_t>(scene.n_spheres + scene.n_planes) * sizeof(float4) + slot_bytes;
+			const size_t lds_bytes = static_cast<size_t>((scene.n_spheres < resident_scalar_scan_from ? scene.n_spheres : 0u) + scene.n_planes) * sizeof(float4) + slot_bytes;
 			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			return variant;
 		}

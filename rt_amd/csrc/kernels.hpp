@@ -193,10 +193,14 @@ namespace rt_hip
 #define RT_HIP_RESIDENT_SCALAR_FROM 40
 #endif
 	constexpr uint32_t resident_scalar_scan_from = RT_HIP_RESIDENT_SCALAR_FROM; // spheres from which the resident kernel scans through the scalar cache (kernels.hip)
-	constexpr uint32_t resident_max_primitives = 1024; // spheres + planes kept whole in LDS by the resident kernel
-	constexpr uint32_t streamed_from_primitives = 1024; // ... which the launch code prefers up to this many (round 5: all it can hold — since its sphere
-													   // scan goes through the scalar cache it is ahead of the streamed kernel's rolling items up to there:
-													   // 1000 spheres x 64 spp 43.4 against 49.1 ms, 700: 29.9 against 34.7; profiles/r05/resident_vs_streamed.txt)
+	constexpr uint32_t resident_max_primitives = 1024; // what the resident kernel keeps in LDS at most: the planes, and the spheres of a scene below resident_scalar_scan_from
+	// The launch code prefers the resident kernel (a pixel tile per wave) up to this many primitives, the streamed kernel's rolling
+	// items beyond.  From resident_scalar_scan_from spheres on the resident kernel reads the sphere table in memory, as the streamed
+	// kernel does, and its LDS holds planes only — so its capacity is no limit to the spheres; what ends its lead is that a tile's
+	// lanes run dry one by one while a trip costs the wave a whole scan: 1 100 spheres x 64 spp 48.2 against 53.3 ms, 2 000: 91.2
+	// against 96.2, 5 000: 250.4 against 248.2, 10 000: 557 against 527, 100 000: 6.3 against 5.5 s
+	// (profiles/r05/resident_beyond_1024_ab.txt; round 5's earlier figures: resident_vs_streamed.txt).
+	constexpr uint32_t streamed_from_primitives = 3000;
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
 	// what a context remembers between launches: workgroups per CU that stay resident, for the persistent (big-scene) kernels
@@ -217,7 +221,8 @@ namespace rt_hip
 	};
 
 	// which kernel launch_render would pick (RT_HIP_KERNEL_*)
-	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective /* the frame's camera is a pinhole or a plain eye-form one: frame_params::pinhole or eye_form == 2 */);
+	uint32_t choose_kernel(const device_scene& scene, uint32_t flags, uint32_t samples_per_pixel, bool perspective /* the frame's camera is a pinhole or a plain eye-form one: frame_params::pinhole or eye_form == 2 */,
+						   uint64_t pixels /* of this rank's rows */);
 
 	// returns the kernel variant launched (RT_HIP_KERNEL_*)
 	uint32_t launch_render(const frame_params& frame,

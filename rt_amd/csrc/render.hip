@@ -194,7 +194,7 @@ rt_hip_status render_device(rt_hip_ctx* ctx, uint32_t width, uint32_t height, ui
 	rolling_buffers rolling;
 	if (!(flags & RT_HIP_FLAG_PREVIEW))
 	{
-		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.pinhole != 0 || f.eye_form == 2u);
+		const uint32_t variant = choose_kernel(ctx->scene, flags, f.samples_per_pixel, f.pinhole != 0 || f.eye_form == 2u, static_cast<uint64_t>(width) * f.local_rows);
 		const bool big_scene = variant == RT_HIP_KERNEL_TILED || variant == RT_HIP_KERNEL_STREAMED;
 		rolling_items = big_scene;
 		queue_params queue = choose_queue(f.samples_per_pixel, width, f.local_rows, big_scene, host_frame, half_chunk_choice(flags), ctx->scene.n_spheres + ctx->scene.n_planes, variant == RT_HIP_KERNEL_STREAMED && ctx->scene.n_spheres >= sparse_launch_min_spheres);
