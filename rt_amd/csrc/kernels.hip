@@ -64,6 +64,12 @@
 #ifndef RT_HIP_WAVES_RESIDENT
 #define RT_HIP_WAVES_RESIDENT 7
 #endif
+// the streamed kernel of frames that fill the device (NS == -3: no cooperative scan of sparse waves, whose four 16-byte loads in flight
+// per lane set the register count of the other build): 80 registers hold its loop, half-chunk items included — config 5 5.47 s at 5
+// waves WITH the cooperative scan, 5.09 without, 4.99 at 6 waves, 5.05 at 7 (profiles/r05/streamed_occupancy_ab.txt)
+#ifndef RT_HIP_WAVES_DENSE
+#define RT_HIP_WAVES_DENSE 6
+#endif
 #ifndef RT_HIP_PERSISTENT_WAVES_CAP
 #define RT_HIP_PERSISTENT_WAVES_CAP 5 // workgroups per CU of the persistent (big-scene) launches: see launch_queue_sm
 #endif
@@ -276,7 +282,8 @@ namespace rt_hip
 		// workgroup's four waves (coalesced dword per lane per column, radius squared on the way in); every wave still
 		// runs its own queue, but the workgroup advances in lock step, one path segment per trip, with barriers around
 		// each tile, until all four waves are done.  NS == -2: `streamed` kernel — the resident loop reading the primitive
-		// table from HBM/L2 with wave-uniform scalar loads.
+		// table from HBM/L2 with wave-uniform scalar loads.  NS == -3: the same without the cooperative scan of sparse waves, for frames
+		// that fill the device (6 waves per SIMD; RT_HIP_WAVES_DENSE above).
 		// SM: scatter table of sm_ray_tracer (RT_HIP_FLAG_SM_MATERIALS) instead of mg_ray_tracer's.
 		// launch bounds: compiled for 7 waves per SIMD.  That raises the compiler's budgets from 64 to 72 vector and from 72
 		// to 88 scalar registers.  With 5..8 spheres in SGPRs and in the resident kernel 64 VGPRs mean scratch
@@ -417,7 +424,7 @@ namespace rt_hip
 		// LDS-resident kernel (+35 % on basic.toml); now they keep the scalar-register kernel, in a build of it that carries
 		// the 18 scalars of the general form INSTEAD of the 18 of the affine one (both would not fit its scalar registers).
 		template <int NS, bool SM, bool HALF = false, int NP = 0, bool GC = false>
-		__global__ __launch_bounds__(block_threads, NS < 0 ? 5 : (NS == 0 ? RT_HIP_WAVES_RESIDENT : (NS >= 6 && NS + NP >= 7 ? RT_HIP_WAVES_MANY : RT_HIP_WAVES_FEW))) void render_queue(const frame_params p,
+		__global__ __launch_bounds__(block_threads, NS == -3 ? RT_HIP_WAVES_DENSE : (NS < 0 ? 5 : (NS == 0 ? RT_HIP_WAVES_RESIDENT : (NS >= 6 && NS + NP >= 7 ? RT_HIP_WAVES_MANY : RT_HIP_WAVES_FEW)))) void render_queue(const frame_params p,
 																	  const queue_params q,
 																	  const small_scene small,
 																	  const device_scene s,
@@ -904,7 +911,7 @@ namespace rt_hip
 						// resident: the LDS copy; streamed: the table in HBM/L2 itself, read with wave-uniform (scalar) loads
 						const float4* const primitives = RESIDENT ? lds : geometry;
 						scan_lds<false>(planes, st.origin, st.dir, RESIDENT ? lds + lds_spheres : geometry + s.n_spheres, s.n_planes, 0);
-						if (NS == -2)
+						if (NS == -2 || NS == -3)
 						{
 							if (scanned_together)
 								spheres = together;
@@ -1512,7 +1519,7 @@ namespace rt_hip
 				constexpr bool fast_arithmetic = false;
 #endif
 				const bool sub_chunk_items = !SM && queue.halves;
-				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -2, SM, fast_arithmetic, sub_chunk_items)];
+				launch_cache::entry& known = cache.persistent[launch_cache::slot(NS == -1 ? 0u : (NS == -2 ? 1u : 2u), SM, fast_arithmetic, sub_chunk_items)];
 				if (known.lds_bytes != lds_bytes || known.per_cu < 1)
 				{
 					int per_cu = 0;
@@ -1528,7 +1535,7 @@ namespace rt_hip
 					// register allocation of a build happens to leave room for a sixth (round 4 saw 6 144 waves instead of 5 120
 					// on one build): the launch's shape should not depend on that.  Measured, it makes no difference either way
 					// (config 5: 5.479 against 5.476 s, profiles/r04/persistent_waves_ab.txt).
-					per_cu = std::min(per_cu, RT_HIP_PERSISTENT_WAVES_CAP);
+					per_cu = std::min(per_cu, NS == -3 ? RT_HIP_WAVES_DENSE : RT_HIP_PERSISTENT_WAVES_CAP);
 					(void)hipGetLastError();
 					known.lds_bytes = lds_bytes;
 					known.per_cu = per_cu;
@@ -1818,7 +1825,13 @@ namespace rt_hip
 		}
 		if (variant == RT_HIP_KERNEL_STREAMED)
 		{
-			launch_queue<-2>(sm, frame, queue, small, scene, grid, 0, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+			// A frame that fills the device — not a thin launch, and at least 4M samples — takes the build without the cooperative scan of
+			// sparse waves: only its last waves run sparse, and the registers that scan costs every other trip are worth 9 % (config 5).
+			const bool dense = queue.lane_cap == 64u && static_cast<uint64_t>(frame.width) * frame.local_rows * frame.samples_per_pixel >= (1ull << 22);
+			if (dense)
+				launch_queue<-3>(sm, frame, queue, small, scene, grid, 0, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+			else
+				launch_queue<-2>(sm, frame, queue, small, scene, grid, 0, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			return variant;
 		}
 		launch_queue<-1>(sm, frame, queue, small, scene, grid, tile_primitives * sizeof(float4), d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);

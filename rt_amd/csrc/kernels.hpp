@@ -211,12 +211,12 @@ namespace rt_hip
 			size_t lds_bytes = 0;
 			int per_cu = 0;
 		};
-		entry persistent[12]; // { tiled, streamed } x { mg, sm scatter table, fast arithmetic } x { whole chunks, sub-chunk items }
+		entry persistent[18]; // { tiled, streamed, streamed for dense frames } x { mg, sm scatter table, fast arithmetic } x { whole chunks, sub-chunk items }
 		// one definition for both builds of kernels.hip (the parity contract and RT_HIP_FAST_BUILD), which are linked into
 		// one library: the build says which arithmetic it is through the argument (the fast build has no sm scatter table)
-		static constexpr unsigned slot(bool streamed, bool sm, bool fast_arithmetic, bool sub_chunk_items)
+		static constexpr unsigned slot(unsigned kernel /* 0 tiled, 1 streamed, 2 streamed for dense frames */, bool sm, bool fast_arithmetic, bool sub_chunk_items)
 		{
-			return (sub_chunk_items ? 6u : 0u) + (streamed ? 3u : 0u) + (fast_arithmetic ? 2u : (sm ? 1u : 0u));
+			return (sub_chunk_items ? 9u : 0u) + 3u * kernel + (fast_arithmetic ? 2u : (sm ? 1u : 0u));
 		}
 	};
 
