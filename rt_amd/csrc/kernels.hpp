@@ -197,10 +197,11 @@ namespace rt_hip
 	// The launch code prefers the resident kernel (a pixel tile per wave) up to this many primitives, the streamed kernel's rolling
 	// items beyond.  From resident_scalar_scan_from spheres on the resident kernel reads the sphere table in memory, as the streamed
 	// kernel does, and its LDS holds planes only — so its capacity is no limit to the spheres; what ends its lead is that a tile's
-	// lanes run dry one by one while a trip costs the wave a whole scan: 1 100 spheres x 64 spp 48.2 against 53.3 ms, 2 000: 91.2
-	// against 96.2, 5 000: 250.4 against 248.2, 10 000: 557 against 527, 100 000: 6.3 against 5.5 s
-	// (profiles/r05/resident_beyond_1024_ab.txt; round 5's earlier figures: resident_vs_streamed.txt).
-	constexpr uint32_t streamed_from_primitives = 3000;
+	// lanes run dry one by one while a trip costs the wave a whole scan.  Against the streamed kernel's build for dense frames
+	// (1080p x 64 spp, kernel ms): 400 spheres 16.8 against 18.4, 700: 29.7 against 31.0, 1 000: 42.9 against 44.9, 1 100: 47.8 against
+	// 48.4, 1 500: 66.5 against 65.8, 2 000: 90.3 against 87.9, 3 000: 141.8 against 130.7 (profiles/r05/resident_vs_dense_streamed.txt;
+	// against the streamed kernel as it was before that build the lead lasted to 4 000 spheres: resident_beyond_1024_ab.txt).
+	constexpr uint32_t streamed_from_primitives = 1300;
 	constexpr uint32_t tile_primitives = 1024;		   // primitives per LDS tile in the tiled kernel
 
 	// what a context remembers between launches: workgroups per CU that stay resident, for the persistent (big-scene) kernels
