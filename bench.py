@@ -206,7 +206,7 @@ def parse_args():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--tiled", action="store_true", help="force the LDS-tiled kernel")
     ap.add_argument("--streamed", action="store_true", help="force the scalar-streamed kernel")
-    ap.add_argument("--resident", action="store_true", help="force the LDS-resident kernel (what a scene of 9 to 704 primitives gets; scenes of up to 8 take the scalar-register kernel otherwise)")
+    ap.add_argument("--resident", action="store_true", help="force the LDS-resident kernel (what a scene of 9 to about 1300 primitives gets; scenes of up to 8 take the scalar-register kernel otherwise)")
     ap.add_argument("--tilt", action="store_true", help="single-process only: look down by 8.5 degrees from (0.2, 1.2, 3.0) instead of the scene's axis-aligned camera — the inverse view-projection then carries rounding noise in w's x / y terms (every frame of an interactive session): the general-camera build of the kernels")
     ap.add_argument("--fast", action="store_true", help="RT_HIP_FLAG_FAST: the tolerance-bound arithmetic (raw v_rsq/v_rcp), a second bench line; never the parity contract")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0, help="0 disables the CPU baseline leg")

@@ -157,7 +157,7 @@ typedef struct rt_hip_stats
 enum
 {
 	RT_HIP_KERNEL_NONE		= 0,
-	RT_HIP_KERNEL_RESIDENT	= 1, /* whole scene resident in LDS for the lifetime of the workgroup (<= 1024 primitives) */
+	RT_HIP_KERNEL_RESIDENT	= 1, /* a pixel tile per wave; planes (and fewer than 40 spheres) resident in LDS for the lifetime of the workgroup (<= 1024 of them) */
 	RT_HIP_KERNEL_TILED		= 2, /* primitives streamed from the SoA columns through LDS in tiles (large scenes) */
 	RT_HIP_KERNEL_SMALL		= 3, /* <= 8 primitives (>= 1 sphere, <= 3 planes): scene in scalar registers, scan fully unrolled */
 	RT_HIP_KERNEL_PREVIEW	= 4, /* RT_HIP_FLAG_PREVIEW: one primary ray per pixel, N.L shading */
@@ -195,7 +195,7 @@ enum
 	 * nothing is hit.  Deterministic: seed, samples_per_pixel and max_bounces are not read; d_rgb_f32 / rgb_f32
 	 * receive the colour before packing.  Partition, gather and assemble work as for the traced frame. */
 	RT_HIP_FLAG_PREVIEW = 1u << 4,
-	/* force the scalar-streamed kernel (it is what scenes above 1024 primitives get from 32 samples per pixel upwards) */
+	/* force the scalar-streamed kernel (it is what scenes above about 1300 primitives get) */
 	RT_HIP_FLAG_FORCE_STREAMED = 1u << 5,
 	/* Contract "v2-fast": the kernels built with the hardware's reciprocal / square-root / reciprocal-square-root
 	 * approximations (about 1 ulp each, no correction steps, no range guards) and with multiply-adds contracted — the
