@@ -741,12 +741,15 @@ def test_the_resident_kernel_beyond_its_lds_capacity(tracer):
     rng = np.random.default_rng(1500)
     spheres, materials, camera = _sphere_field(rng, 1200)
     plane_rows = [(0.0, 1.0, 0.0, 0.002, 0)]
-    for width, height, spp, flags, expected in ((2048, 1024, 2, 0, "resident"), (2048, 1024, 2, FORCE_STREAMED, "streamed"), (200, 113, 33, 0, "streamed"),
+    # (the streamed launches of the big frame are the streamed kernel's build for dense frames — no cooperative scan, 6 waves per SIMD —
+    # with mg's and with sm's scatter table, in whole chunks and in runs of 8 samples; the small frame's is the cooperative build)
+    for width, height, spp, flags, expected in ((2048, 1024, 2, 0, "resident"), (2048, 1024, 2, FORCE_STREAMED, "streamed"), (2048, 1024, 2, FORCE_STREAMED | SM, "streamed"),
+                                                (1024, 512, 24, FORCE_STREAMED | capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, "streamed"), (200, 113, 33, 0, "streamed"),
                                                 (200, 113, 33, FORCE_RESIDENT, "resident"), (97, 41, 20, FORCE_RESIDENT | capi.RT_HIP_FLAG_FORCE_HALF_CHUNKS, "resident")):
         ivp = camera.describe(width, height).inverse_view_projection[:]
         pod = rt_amd.scene_from_arrays(spheres, plane_rows, materials, samples_per_pixel=spp, max_bounces=6, inverse_view_projection=ivp)
         got_rgba, got_rgb, stats = tracer.render(pod, width, height, seed=15, flags=flags, want_rgb=True)
-        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=15)
+        want_rgba, want_rgb, want_stats = oracle.render(pod, width, height, seed=15, sm_materials=bool(flags & SM))
         assert stats["kernel"] == expected, (width, height, spp, flags, stats["kernel"])
         assert_bit_exact(got_rgba, got_rgb, want_rgba, want_rgb, f"1200 spheres + a plane, {width}x{height}x{spp}, flags {flags}")
         assert stats["segments"] == want_stats["segments"]
