@@ -441,7 +441,10 @@ namespace rt_hip
 			float4* const lds_shading = lds + scalar_max_spheres;
 			constexpr bool RESIDENT = NS == 0; // all primitives in LDS
 			// [NS == 0] from resident_scalar_scan_from spheres on the sphere scan reads the table in memory (scalar loads): only the planes are staged
-			const bool spheres_in_lds = RESIDENT && s.n_spheres < resident_scalar_scan_from;
+			// (a build of its own, NP == 1: the scalar-load scan keeps two groups of four spheres in 32 scalar registers, which the
+			// LDS-scan build — scenes below the threshold — has for the frame's constants instead)
+			constexpr bool RESIDENT_SCALAR_SCAN = NS == 0 && NP == 1;
+			const bool spheres_in_lds = RESIDENT && !RESIDENT_SCALAR_SCAN;
 			const uint32_t lds_spheres = spheres_in_lds ? s.n_spheres : 0u;
 			const uint32_t table_float4s = NS > 0 ? small_table_float4s : (RESIDENT ? lds_spheres + s.n_planes : (NS == -1 ? tile_primitives : 0u));
 			if (NS > 0)
@@ -473,7 +476,14 @@ namespace rt_hip
 			// finite eye (an orthographic frustum: nothing rt's camera can produce) takes the LDS-resident kernel, which carries all
 			// three forms — together with seven spheres their scalars do not fit the scalar registers, and hipcc then reloads the
 			// SPHERES from the argument block inside the loop (round 5: dielectric.toml through a tilted camera 3.85 ms).
-			constexpr bool PINHOLE_ONLY = NS > 0 && !GC, EYE_ONLY = NS > 0 && GC;
+			// The LDS-resident kernel is built per scan, and its LDS-scan build per camera form too: as ONE kernel it carried the three camera
+			// forms' constants AND the scalar-load scan's two groups of four spheres (32 scalar registers), and its loop reloaded the frame's
+			// constants from the argument block (30 s_load and 35 v_readlane of spilled scalars per loop body).  NP == 0: the LDS scan (scenes
+			// below resident_scalar_scan_from spheres), GC = "the frame is not a pinhole's" (eye or homogeneous form, chosen at run time);
+			// NP == 1: the scalar-load scan, all forms at run time as before (split by form it gained nothing and lost 4 % through a tilted
+			// camera).  12 spheres 1.23 -> 1.15 ms, 32: 2.06 -> 2.01, basic.toml forced here 2.89 -> 2.72 (profiles/r05/resident_forms_ab.txt).
+			constexpr bool RESIDENT_LDS_SCAN = NS == 0 && NP == 0;
+			constexpr bool PINHOLE_ONLY = (NS > 0 || RESIDENT_LDS_SCAN) && !GC, EYE_ONLY = NS > 0 && GC, NEVER_PINHOLE = RESIDENT_LDS_SCAN && GC;
 			const uint32_t lane = threadIdx.x & 63u;
 			const uint32_t wave = threadIdx.x >> 6;
 			const uint32_t chunk_items = q.chunks << q.pixels_log2;	   // chunks of one pixel tile: P x K
@@ -924,7 +934,7 @@ namespace rt_hip
 						// take their operands from scalar registers, and neither the LDS pipe nor four vector registers per sphere in
 						// flight are spent on it (64 spheres x 256 spp 12.9 -> 12.5 ms, 200 spheres 9.6 -> 8.7, 700 33.3 -> 29.9; below
 						// about 40 the LDS copy is ahead: 12 spheres 1.17 against 1.24 ms; profiles/r05/resident_scalar_ab.txt)
-						else if (NS == 0 && s.n_spheres >= resident_scalar_scan_from)
+						else if (RESIDENT_SCALAR_SCAN)
 							scan_streamed_spheres(spheres, st.origin, st.dir, geometry, s.n_spheres);
 						else
 							scan_lds<true>(spheres, st.origin, st.dir, primitives, s.n_spheres, 0);
@@ -978,7 +988,7 @@ namespace rt_hip
 					st.chunk_sum = { 0.0f, 0.0f, 0.0f };
 					{
 						const float fx = static_cast<float>(lx), fy = static_cast<float>(gy);
-						if (PINHOLE_ONLY || (!EYE_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
+						if (PINHOLE_ONLY || (!EYE_ONLY && !NEVER_PINHOLE && p.pinhole)) // (wave-uniform: a kernel argument)
 						{
 							st.base_x = fma(p.ray_d1[0], fx, fma(p.ray_d2[0], fy, p.ray_d0[0]));
 							st.base_y = fma(p.ray_d1[1], fx, fma(p.ray_d2[1], fy, p.ray_d0[1]));
@@ -1241,7 +1251,7 @@ namespace rt_hip
 								st.counter = 0u; // (the sample draws nothing: back to the window's start)
 							}
 						}
-						if (PINHOLE_ONLY || (!EYE_ONLY && p.pinhole)) // (wave-uniform: a kernel argument)
+						if (PINHOLE_ONLY || (!EYE_ONLY && !NEVER_PINHOLE && p.pinhole)) // (wave-uniform: a kernel argument)
 						{
 							// rt's camera: the near-to-far vector from the pixel's base and the jitter, the near point from it (contract
 							// v4; constants from the host).  The LDS / big-scene kernels carry both forms; a scalar-register kernel is
@@ -1820,7 +1830,12 @@ namespace rt_hip
 		if (variant == RT_HIP_KERNEL_RESIDENT)
 		{
 			const size_t lds_bytes = static_cast<size_t>((scene.n_spheres < resident_scalar_scan_from ? scene.n_spheres : 0u) + scene.n_planes) * sizeof(float4) + slot_bytes;
-			launch_queue<0>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+			if (scene.n_spheres >= resident_scalar_scan_from) // (the scalar-load scan: one build for every camera form)
+				launch_queue<0, 1, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+			else if (frame.pinhole)
+				launch_queue<0, 0, false>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
+			else
+				launch_queue<0, 0, true>(sm, frame, queue, small, scene, grid, lds_bytes, d_rgba8, d_rgb_f32, d_counters, rolling, compute_units, cache, stream);
 			return variant;
 		}
 		if (variant == RT_HIP_KERNEL_STREAMED)
